@@ -1,0 +1,358 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: box-attention fwd+bwd at BoxeR-R50 COCO shapes.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one box-attention forward + backward (boxer_amd.ops.box_attn_forward +
+box_attn_backward, i.e. the reference's native boundary e2edet.ops) over one per-GPU batch
+of synthetic input, inputs resident in HBM.  The backward includes the grad_value zero-fill
+and, in bf16 mode, the fp32->bf16 conversion of grad_value (they are part of the op).
+
+Metric (BASELINE.json): Gsample-points/s, one sample point = one (b, query, head, level,
+point) bilinear sample of C=32 channels; NP = B*Lq*H*L*P per step and GPU.
+Default workload = BASELINE.json configs[1] ("C2" in SURVEY.md 8(d)): 4 levels
+(100/50/25/13)^2, d=256, 8 heads, 2x2 grid, Lq = S = 13 294 queries, B = 2 images per GPU,
+bf16 storage (value / grad_out / out / grad_value bf16; locations, weights, accumulation fp32).
+
+Multi-GPU: the path shards over images with no data-path collective: every
+rank processes its own B images; value = total points of all ranks / max-over-ranks time
+("scaling": "weak").  The only collectives are the timing barrier and the MAX reduction.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" (dominant kernel vs the 8 TB/s HBM peak) and "cpu_baseline" (the pure-PyTorch
+grid_sample formulation timed on the host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# name: (levels, Lq ("S" = one query per pixel), points per level P, kind)
+WORKLOADS = {
+    "C2": ([(100, 100), (50, 50), (25, 25), (13, 13)], "S", 4, "box"),
+    "C2p": ([(100, 167), (50, 84), (25, 42), (13, 21)], "S", 4, "box"),
+    "C3": ([(100, 100), (50, 50), (25, 25), (13, 13)], 300, 16, "instance"),
+    "C3p": ([(100, 167), (50, 84), (25, 42), (13, 21)], 300, 196, "instance"),
+    "C3pp": ([(100, 167), (50, 84), (25, 42), (13, 21)], 300, 4, "box"),
+    "C5p": ([(234, 234), (117, 117)], "S", 4, "box"),
+}
+H_HEADS, C_HEAD, BATCH = 8, 32, 2
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------------------
+def encoder_ref_windows(levels, device, ref_size=4.0):
+    """Pixel-centre reference windows (cx, cy, ref_size/W_l, ref_size/H_l), one per pixel of
+    every level, as BoxeR's encoder builds them (box_transformer.py:70-116, no padding)."""
+    out = []
+    for (h, w) in levels:
+        ys = (torch.arange(1, h + 1, device=device, dtype=torch.float32) - 0.5) / (h + 1e-6)
+        xs = (torch.arange(1, w + 1, device=device, dtype=torch.float32) - 0.5) / (w + 1e-6)
+        cy, cx = torch.meshgrid(ys, xs, indexing="ij")
+        size = torch.tensor([ref_size / w, ref_size / h], device=device).expand(h * w, 2)
+        out.append(torch.cat([cx.reshape(-1, 1), cy.reshape(-1, 1), size], dim=1))
+    return torch.cat(out, dim=0)
+
+
+def make_inputs(workload, dtype, device, family="model", batch=BATCH, seed=0):
+    """Returns dict(value, shapes, lsi, loc, attn[, level_w], grad_out[, grad_mask], dims).
+
+    family "model": reference windows + N(0,1) box offsets + softmax(N(0,1)) weights run
+    through the BoxeR geometry (grid = centre + kernel_index * relu(size)), value ~ N(0,1);
+    family "test": i.i.d. uniform locations, normalised uniform weights, value = rand*0.01
+    (the reference's test distribution, tests/box_attn_test.py:57-60) -- worst-case locality.
+    """
+    levels, lq, P, kind = WORKLOADS[workload]
+    L = len(levels)
+    S = sum(h * w for h, w in levels)
+    Lq = S if lq == "S" else lq
+    H, C, B = H_HEADS, C_HEAD, batch
+    g = torch.Generator(device=device).manual_seed(seed)
+    shapes = torch.tensor(levels, dtype=torch.long, device=device)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    k = int(round(math.sqrt(P)))
+    assert k * k == P
+
+    if family == "model":
+        value = torch.randn(B, S, H, C, device=device, generator=g)
+        if lq == "S":
+            ref = encoder_ref_windows(levels, device)[None].expand(B, -1, -1)
+        else:
+            ctr = 0.05 + 0.9 * torch.rand(B, Lq, 2, device=device, generator=g)
+            wh = 0.05 + 0.45 * torch.rand(B, Lq, 2, device=device, generator=g)
+            ref = torch.cat([ctr, wh], dim=-1)
+        ref = ref[:, :, None, None, :]                                   # (B,Lq,1,1,4)
+        off = torch.randn(B, Lq, H, L, 4, device=device, generator=g)
+        boxes = ref + off / 8 * ref[..., [2, 3, 2, 3]]
+        half = (k - 1) / 2.0
+        ticks = torch.linspace(-half, half, k, device=device)
+        ky, kx = torch.meshgrid(ticks, ticks, indexing="ij")
+        kidx = torch.stack([kx, ky], -1).reshape(-1, 2) / k              # (P,2)
+        loc = boxes[..., None, :2] + kidx * torch.relu(boxes[..., None, 2:])
+        logits = torch.randn(B, Lq, H, L, P, device=device, generator=g)
+        attn = torch.softmax(logits.view(B, Lq, H, L * P), -1).view(B, Lq, H, L, P)
+        level_w = torch.softmax(logits, dim=3)
+    elif family == "test":
+        value = torch.rand(B, S, H, C, device=device, generator=g) * 0.01
+        loc = torch.rand(B, Lq, H, L, P, 2, device=device, generator=g)
+        a = torch.rand(B, Lq, H, L, P, device=device, generator=g) + 1e-5
+        attn = a / a.sum((-1, -2), keepdim=True)
+        level_w = a / a.sum(-2, keepdim=True)
+    else:
+        raise ValueError(family)
+    grad_out = torch.randn(B, Lq, H * C, device=device, generator=g)
+    d = dict(value=value.to(dtype).contiguous(), shapes=shapes, lsi=lsi,
+             loc=loc.float().contiguous(), attn=attn.float().contiguous(),
+             grad_out=grad_out.to(dtype).contiguous(), kind=kind,
+             dims=dict(B=B, S=S, H=H, C=C, L=L, Lq=Lq, P=P))
+    if dtype == torch.float64:
+        d["loc"], d["attn"] = d["loc"].double(), d["attn"].double()
+    if kind == "instance":
+        d["level_w"] = level_w.to(d["attn"].dtype).contiguous()
+        d["grad_mask"] = torch.randn(B, Lq, P, H * C, device=device, generator=g).to(dtype)
+    return d
+
+
+def n_points(dims):
+    return dims["B"] * dims["Lq"] * dims["H"] * dims["L"] * dims["P"]
+
+
+def algorithmic_bytes(dims, kind, elem):
+    """Compulsory HBM bytes of one forward / one backward: every tensor once,
+    value read capped at what is touched, grad_value written as fp32, zero-fills not counted."""
+    B, S, H, C, L, Lq, P = (dims[k] for k in ("B", "S", "H", "C", "L", "Lq", "P"))
+    NP = B * Lq * H * L * P
+    inst = kind == "instance"
+    Vr = min(elem * B * S * H * C, elem * 4 * C * NP)
+    W = (16 if inst else 12) * NP
+    O = elem * B * Lq * H * C
+    M = elem * B * Lq * P * H * C if inst else 0
+    fwd = Vr + W + O + M
+    bwd = Vr + W + O + M + 4 * B * S * H * C + W
+    return fwd, bwd
+
+
+# --------------------------------------------------------------------------------------
+# the timed step
+# --------------------------------------------------------------------------------------
+def make_step(inp):
+    from boxer_amd import ops
+    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
+                                                  "grad_out"))
+    if inp["kind"] == "box":
+        def step():
+            out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+            grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+            return out, grads
+    else:
+        lw, gm = inp["level_w"], inp["grad_mask"]
+
+        def step():
+            out = ops.instance_attn_forward(v, sh, ls, loc, attn, lw, 64)
+            grads = ops.instance_attn_backward(v, sh, ls, loc, attn, lw, go, gm, 64)
+            return out, grads
+    return step
+
+
+def time_phases(inp, iters=20):
+    """fwd-only and bwd-only device time (ms, median) with events on the op's stream."""
+    from boxer_amd import ops
+    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
+                                                  "grad_out"))
+    if inp["kind"] == "box":
+        fwd = lambda: ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+        bwd = lambda: ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+    else:
+        lw, gm = inp["level_w"], inp["grad_mask"]
+        fwd = lambda: ops.instance_attn_forward(v, sh, ls, loc, attn, lw, 64)
+        bwd = lambda: ops.instance_attn_backward(v, sh, ls, loc, attn, lw, go, gm, 64)
+    res = {}
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        res[name] = ts[len(ts) // 2]
+    return res
+
+
+def kernel_profile(step, steps):
+    """Average duration of the op's main kernels, measured with HIP events that the library
+    records around them on the launch stream (boxattn_profile_*; see include/boxattn.h)."""
+    from boxer_amd import _lib
+    if not hasattr(_lib, "profile_begin"):
+        return None
+    _lib.profile_begin()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return _lib.profile_end()
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the pure-PyTorch grid_sample formulation on the host cores
+# --------------------------------------------------------------------------------------
+def cpu_baseline(workload, budget_s=20.0):
+    from oracle import torch_fallback as tf
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    levels, lq, P, kind = WORKLOADS[workload]
+    # bounded sample: ONE image of the workload (B=1) -- same shapes otherwise
+    inp = make_inputs(workload, torch.float32, "cpu", family="model", batch=1, seed=0)
+    v = inp["value"].requires_grad_()
+    loc = inp["loc"].requires_grad_()
+    attn = inp["attn"].requires_grad_()
+    np_ = n_points(inp["dims"])
+
+    def once():
+        for t in (v, loc, attn):
+            t.grad = None
+        if kind == "box":
+            out = tf.box_attn(v, inp["shapes"], loc, attn)
+            out.backward(inp["grad_out"])
+        else:
+            lw = inp["level_w"]
+            out, mask = tf.instance_attn(v, inp["shapes"], loc, attn, lw)
+            torch.autograd.backward([out, mask], [inp["grad_out"], inp["grad_mask"]])
+
+    t0 = time.perf_counter()
+    once()                                            # warm-up (also sizes the loop)
+    first = time.perf_counter() - t0
+    iters = max(1, min(20, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": np_ / dt / 1e9, "unit": "Gsample-points/s", "cores": cores,
+            "kind": "port",
+            "sample": "%s fp32, B=1 image (%d points), fwd+bwd via autograd of the grid_sample "
+                      "formulation (oracle/torch_fallback.py), %d iterations, %.2f s/iter, "
+                      "torch threads=%d" % (workload, np_, iters, dt, cores)}
+
+
+# --------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--inputs", default="model", choices=["model", "test"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    from boxer_amd import _lib
+    _lib.set_variant(args.variant)
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+    # every rank owns its own images (different seed): data-parallel shard, no exchange
+    inp = make_inputs(args.workload, dtype, device, family=args.inputs, seed=rank)
+    step = make_step(inp)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    np_rank = n_points(inp["dims"])
+    total_points = np_rank * world * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_points / elapsed / 1e9
+
+    phases = time_phases(inp)
+    prof = kernel_profile(step, min(args.steps, 20))
+    elem = 2 if dtype == torch.bfloat16 else 4
+    b_fwd, b_bwd = algorithmic_bytes(inp["dims"], inp["kind"], elem)
+
+    if rank == 0:
+        # dominant kernel = the backward sampling/scatter kernel
+        if prof and prof.get("bwd_ms"):
+            dom_ms, src = prof["bwd_ms"], "HIP events around the backward kernel"
+        else:
+            dom_ms, src = phases["bwd"], "HIP events around the backward call"
+        achieved = b_bwd / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "bwd_fast_kernel", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": b_bwd,
+                    "avg_launch_ms": round(dom_ms, 4), "timing": src,
+                    "fwd_bwd": {"algorithmic_bytes": b_fwd + b_bwd,
+                                "achieved_GBs": round((b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9, 1),
+                                "frac": round((b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9
+                                              / HBM_PEAK_GBS, 4)},
+                    "fwd_ms": round(phases["fwd"], 4), "bwd_ms": round(phases["bwd"], 4)}
+        if prof:
+            roofline["kernels"] = prof
+        line = {
+            "metric": "box-attn fwd+bwd Gsample-points/s + achieved HBM GB/s, BoxeR-R50 COCO shapes",
+            "value": round(value, 4), "unit": "Gsample-points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s: %s-attn fwd+bwd, levels %s, Lq=%d, H=%d, C=%d, P=%d, "
+                                   "B=%d images per GPU, inputs=%s" % (
+                                       args.workload, inp["kind"],
+                                       "/".join("%dx%d" % hw for hw in WORKLOADS[args.workload][0]),
+                                       inp["dims"]["Lq"], H_HEADS, C_HEAD, inp["dims"]["P"], BATCH,
+                                       args.inputs),
+                       "points_per_step_per_gpu": np_rank, "parallelism": "dp%d" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""Loader (and in-tree builder) of the C-ABI HIP library ``libboxattn_hip.so``.
+
+The library is the product: there is no CPU or PyTorch fallback behind it.  If it cannot be
+found or loaded, every op raises -- nothing here ever imports ``oracle/``.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_NAME = "libboxattn_hip.so"
+LIB_PATH = os.path.join(_PKG, LIB_NAME)
+SOURCES = ["boxattn_capi.hip"]
+HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-shared", "-Wall", "-Wno-pass-failed"]
+
+_lib = None
+
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+_DIMS = [_i] * 7                      # B, S, H, C, L, Lq, P
+_SIGNATURES = {
+    # name: argtypes  (see include/boxattn.h)
+    "boxattn_fwd": [_vp] * 5 + _DIMS + [_vp, _vp],
+    "boxattn_bwd": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp],
+    "instattn_fwd": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp],
+    "instattn_bwd": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp],
+}
+EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
+           "boxattn_profile_begin", "boxattn_profile_end"] + [
+    "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build %s" % LIB_NAME)
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(_CSRC, f) for f in SOURCES + HEADERS]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "boxattn.h"))
+    return any(os.path.getmtime(s) > built for s in srcs if os.path.exists(s))
+
+
+def build(force=False, verbose=False):
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
+    if not (force or needs_build()):
+        return LIB_PATH
+    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [
+        os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def load():
+    """Return the ctypes handle; raises RuntimeError if the HIP library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s is missing. Build it with `python setup.py build_ext --inplace` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). boxer_amd has no CPU "
+            "fallback by design." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.boxattn_abi_version.restype = _i
+    lib.boxattn_build_info.restype = ctypes.c_char_p
+    lib.boxattn_set_variant.argtypes = [_i]
+    lib.boxattn_set_variant.restype = _i
+    for stem, args in _SIGNATURES.items():
+        for suf in ("f32", "f64", "bf16"):
+            fn = getattr(lib, "%s_%s" % (stem, suf))
+            extra = [_vp] if (suf == "bf16" and stem.endswith("bwd")) else []
+            fn.argtypes = args[:-1] + extra + args[-1:]        # ..., [grad_value_ws], stream
+            fn.restype = _i
+    if lib.boxattn_abi_version() != 1:
+        raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def build_info():
+    return load().boxattn_build_info().decode()
+
+
+def set_variant(v):
+    """0 = auto, 1 = generic kernels only, 2 = fast kernels only (error if not eligible)."""
+    return load().boxattn_set_variant(int(v))
+
+
+def profile_begin():
+    """Start bracketing the library's main kernels with hipEvents (bench.py)."""
+    load().boxattn_profile_begin()
+
+
+def profile_end():
+    """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches): average kernel duration in ms."""
+    fs, bs = ctypes.c_double(0), ctypes.c_double(0)
+    fn, bn = ctypes.c_int(0), ctypes.c_int(0)
+    load().boxattn_profile_end(ctypes.byref(fs), ctypes.byref(fn), ctypes.byref(bs),
+                               ctypes.byref(bn))
+    return {"fwd_ms": fs.value / fn.value if fn.value else None, "fwd_launches": fn.value,
+            "bwd_ms": bs.value / bn.value if bn.value else None, "bwd_launches": bn.value}

@@ -1,0 +1,391 @@
+// C ABI of the box-attention operator (declared in include/boxattn.h): argument checks,
+// kernel-variant choice and launches.  No torch / ATen types anywhere in this library.
+//
+// Replaces the reference host code e2edet/module/ops/src/box_attn/box_attn.cu:15-135 and
+// e2edet/module/ops/src/instance_attn/instance_attn.cu:15-157 (checks, output zero-fill,
+// launch) and the launchers box_attn_kernel.cuh:1078-1123, 1126-1505.
+#include "../../include/boxattn.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
+#include "boxattn_fast.h"
+#include "boxattn_generic.h"
+
+using namespace boxattn;
+
+namespace {
+
+int g_variant = 0;   // 0 auto, 1 generic only, 2 fast (fails if the shape does not qualify)
+
+inline int ceil_div_sz(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+struct Dims {
+    int B, S, H, C, L, Lq, P;
+    bool valid() const
+    {
+        return B >= 0 && S >= 0 && H > 0 && C > 0 && L > 0 && Lq >= 0 && P > 0;
+    }
+    size_t n_qh() const { return (size_t)B * Lq * H; }
+    size_t n_value() const { return (size_t)B * S * H * C; }
+    bool empty() const { return n_qh() == 0; }
+};
+
+// Which G (lanes per (query, head)) the fast kernels are instantiated for, VEC = 4.
+inline int fast_group(const Dims &d)
+{
+    if (d.C % 4 != 0 || d.L > kMaxLevels) return 0;
+    const int g = d.C / 4;
+    return (g == 4 || g == 8 || g == 16) ? g : 0;
+}
+
+template <typename ST>
+bool fast_ok(const Dims &d, const void *value, const void *loc, const void *a, const void *b,
+             const void *c)
+{
+    if (g_variant == 1) return false;
+    if (fast_group(d) == 0) return false;
+    const size_t va = 4 * sizeof(ST);
+    return aligned(value, va) && aligned(loc, 8) && aligned(a, va) && aligned(b, va) &&
+           aligned(c, va);
+}
+
+inline int finish()
+{
+    return (int)hipGetLastError();
+}
+
+// ---- optional kernel timing (boxattn_profile_begin/_end) -------------------------------
+struct EventPair { hipEvent_t a, b; };
+struct Profile {
+    bool on = false;
+    std::vector<EventPair> fwd, bwd;
+} g_prof;
+constexpr size_t kMaxProfiled = 4096;
+
+struct ScopedKernelTimer {            // brackets one kernel launch when profiling is on
+    hipStream_t st;
+    EventPair ev{};
+    std::vector<EventPair> *dst = nullptr;
+    ScopedKernelTimer(std::vector<EventPair> &v, hipStream_t s) : st(s)
+    {
+        if (!g_prof.on || v.size() >= kMaxProfiled) return;
+        if (hipEventCreate(&ev.a) != hipSuccess) return;
+        if (hipEventCreate(&ev.b) != hipSuccess) { (void)hipEventDestroy(ev.a); return; }
+        dst = &v;
+        (void)hipEventRecord(ev.a, st);
+    }
+    ~ScopedKernelTimer()
+    {
+        if (!dst) return;
+        (void)hipEventRecord(ev.b, st);
+        dst->push_back(ev);
+    }
+};
+
+inline void drain(std::vector<EventPair> &v, double *ms_sum, int *n)
+{
+    double sum = 0;
+    int cnt = 0;
+    for (auto &e : v) {
+        float ms = 0;
+        if (hipEventSynchronize(e.b) == hipSuccess &&
+            hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            sum += ms;
+            ++cnt;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    v.clear();
+    if (ms_sum) *ms_sum = sum;
+    if (n) *n = cnt;
+}
+
+// ------------------------------------------------------------------------------ forward
+template <typename ST, bool INST>
+int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
+               const typename Storage<ST>::compute *loc,
+               const typename Storage<ST>::compute *w_sp,
+               const typename Storage<ST>::compute *w_lv, const Dims &d, ST *out, ST *mask,
+               hipStream_t st)
+{
+    if (!d.valid()) return (int)hipErrorInvalidValue;
+    if (d.empty()) return 0;                                   // no queries: nothing to write
+    if (!shapes || !lsi || !loc || !w_sp || !out || (INST && (!w_lv || !mask)))
+        return (int)hipErrorInvalidValue;
+    const size_t n_qh = d.n_qh();
+    if (d.n_value() == 0) {                                    // no pixels: every sample is 0
+        hipError_t e = hipMemsetAsync(out, 0, n_qh * d.C * sizeof(ST), st);
+        if (e == hipSuccess && INST)
+            e = hipMemsetAsync(mask, 0, n_qh * d.C * d.P * sizeof(ST), st);
+        return (int)e;
+    }
+    if (!value) return (int)hipErrorInvalidValue;
+    if constexpr (!std::is_same<ST, double>::value) {
+        if (fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out,
+                        out)) {
+            const int G = fast_group(d);
+            const int pairs = kWave / G;
+            const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
+            ScopedKernelTimer timer(g_prof.fwd, st);
+#define BOXATTN_FWD_CASE(GG)                                                                  \
+    case GG:                                                                                  \
+        hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, st, \
+                           value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P,   \
+                           out, mask, n_qh);                                                  \
+        break;
+            switch (G) {
+                BOXATTN_FWD_CASE(4)
+                BOXATTN_FWD_CASE(8)
+                BOXATTN_FWD_CASE(16)
+            }
+#undef BOXATTN_FWD_CASE
+            return finish();
+        }
+        if (g_variant == 2) return (int)hipErrorInvalidValue;
+    }
+    const size_t n = n_qh * d.C;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)1 << 20);
+    ScopedKernelTimer timer(g_prof.fwd, st);
+    hipLaunchKernelGGL((fwd_generic_kernel<ST, INST>), dim3(blocks), dim3(256), 0, st, value,
+                       shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.C, d.L, d.Lq, d.P, out, mask,
+                       n);
+    return finish();
+}
+
+// ----------------------------------------------------------------------------- backward
+// GV = accumulation buffer for grad_value (the output itself for f32/f64, scratch for bf16)
+template <typename ST, bool INST>
+int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
+               const typename Storage<ST>::compute *loc,
+               const typename Storage<ST>::compute *w_sp,
+               const typename Storage<ST>::compute *w_lv, const ST *grad_out,
+               const ST *grad_mask, const Dims &d, ST *grad_value,
+               typename Storage<ST>::compute *grad_loc, typename Storage<ST>::compute *grad_sp,
+               typename Storage<ST>::compute *grad_lv,
+               typename Storage<ST>::compute *grad_value_acc, hipStream_t st)
+{
+    typedef typename Storage<ST>::compute T;
+    if (!d.valid()) return (int)hipErrorInvalidValue;
+    const size_t nv = d.n_value();
+    const size_t n_qh = d.n_qh();
+    if (nv) {
+        if (!grad_value || !grad_value_acc) return (int)hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(grad_value_acc, 0, nv * sizeof(T), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (n_qh) {
+        if (!shapes || !lsi || !loc || !w_sp || !grad_out || !grad_loc || !grad_sp ||
+            (INST && (!w_lv || !grad_mask || !grad_lv)))
+            return (int)hipErrorInvalidValue;
+        if (!nv) {                                             // no pixels: all gradients 0
+            const size_t np = n_qh * d.L * d.P;
+            hipError_t e = hipMemsetAsync(grad_loc, 0, 2 * np * sizeof(T), st);
+            if (e == hipSuccess) e = hipMemsetAsync(grad_sp, 0, np * sizeof(T), st);
+            if (e == hipSuccess && INST) e = hipMemsetAsync(grad_lv, 0, np * sizeof(T), st);
+            return (int)e;
+        }
+        if (!value) return (int)hipErrorInvalidValue;
+    }
+    if (n_qh && nv) {
+        ScopedKernelTimer timer(g_prof.bwd, st);
+        bool done = false;
+        if constexpr (!std::is_same<ST, double>::value) {
+            if (fast_ok<ST>(d, value, loc, grad_out,
+                            INST ? (const void *)grad_mask : (const void *)grad_out,
+                            grad_loc)) {
+                const int G = fast_group(d);
+                const int pairs = kWave / G;
+                const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
+#define BOXATTN_BWD_CASE(GG)                                                                  \
+    case GG:                                                                                  \
+        hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, st, \
+                           value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S,    \
+                           d.H, d.L, d.Lq, d.P, grad_value_acc, grad_loc, grad_sp, grad_lv,  \
+                           n_qh);                                                             \
+        break;
+                switch (G) {
+                    BOXATTN_BWD_CASE(4)
+                    BOXATTN_BWD_CASE(8)
+                    BOXATTN_BWD_CASE(16)
+                }
+#undef BOXATTN_BWD_CASE
+                done = true;
+            } else if (g_variant == 2) {
+                return (int)hipErrorInvalidValue;
+            }
+        }
+        if (!done) {
+            const int blocks = (int)std::min<size_t>((n_qh + 3) / 4, (size_t)1 << 20);
+            hipLaunchKernelGGL((bwd_generic_kernel<ST, INST>), dim3(blocks), dim3(256), 0, st,
+                               value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S,
+                               d.H, d.C, d.L, d.Lq, d.P, grad_value_acc, grad_loc, grad_sp,
+                               grad_lv, n_qh);
+        }
+        int rc = finish();
+        if (rc) return rc;
+    }
+    if constexpr (std::is_same<ST, bf16_t>::value) {
+        if (nv) {
+            const int blocks = (int)std::min<size_t>((nv / 4 + 255) / 256 + 1, 256 * 16);
+            hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st,
+                               grad_value_acc, grad_value, nv);
+            return finish();
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int boxattn_abi_version(void) { return BOXATTN_ABI_VERSION; }
+
+const char *boxattn_build_info(void)
+{
+    return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
+           " | kernels: generic{f32,f64,bf16}, fast{f32,bf16} VEC=4 G={4,8,16}";
+}
+
+int boxattn_profile_begin(void)
+{
+    drain(g_prof.fwd, nullptr, nullptr);
+    drain(g_prof.bwd, nullptr, nullptr);
+    g_prof.on = true;
+    return 0;
+}
+
+int boxattn_profile_end(double *fwd_ms_sum, int *fwd_launches, double *bwd_ms_sum,
+                        int *bwd_launches)
+{
+    g_prof.on = false;
+    drain(g_prof.fwd, fwd_ms_sum, fwd_launches);
+    drain(g_prof.bwd, bwd_ms_sum, bwd_launches);
+    return 0;
+}
+
+int boxattn_set_variant(int variant)
+{
+    const int old = g_variant;
+    g_variant = variant;
+    return old;
+}
+
+#define DIMS Dims{B, S, H, C, L, Lq, P}
+#define ST_ (hipStream_t) stream
+
+int boxattn_fwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                    const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                    int Lq, int P, float *out, void *stream)
+{
+    return launch_fwd<float, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out, nullptr,
+                                    ST_);
+}
+int boxattn_fwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                    const double *loc, const double *attn, int B, int S, int H, int C, int L,
+                    int Lq, int P, double *out, void *stream)
+{
+    return launch_fwd<double, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out,
+                                     nullptr, ST_);
+}
+int boxattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                     int Lq, int P, uint16_t *out, void *stream)
+{
+    return launch_fwd<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out,
+                                     nullptr, ST_);
+}
+
+int boxattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                    const float *loc, const float *attn, const float *grad_out, int B, int S,
+                    int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                    float *grad_attn, void *stream)
+{
+    return launch_bwd<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
+                                    DIMS, grad_value, grad_loc, grad_attn, nullptr, grad_value,
+                                    ST_);
+}
+int boxattn_bwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                    const double *loc, const double *attn, const double *grad_out, int B,
+                    int S, int H, int C, int L, int Lq, int P, double *grad_value,
+                    double *grad_loc, double *grad_attn, void *stream)
+{
+    return launch_bwd<double, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
+                                     DIMS, grad_value, grad_loc, grad_attn, nullptr,
+                                     grad_value, ST_);
+}
+int boxattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *attn, const uint16_t *grad_out, int B,
+                     int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                     float *grad_loc, float *grad_attn, float *grad_value_ws, void *stream)
+{
+    return launch_bwd<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
+                                     DIMS, grad_value, grad_loc, grad_attn, nullptr,
+                                     grad_value_ws, ST_);
+}
+
+int instattn_fwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *spatial_w, const float *level_w, int B,
+                     int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
+                     void *stream)
+{
+    return launch_fwd<float, true>(value, shapes, lsi, loc, spatial_w, level_w, DIMS, out,
+                                   mask_out, ST_);
+}
+int instattn_fwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                     const double *loc, const double *spatial_w, const double *level_w, int B,
+                     int S, int H, int C, int L, int Lq, int P, double *out, double *mask_out,
+                     void *stream)
+{
+    return launch_fwd<double, true>(value, shapes, lsi, loc, spatial_w, level_w, DIMS, out,
+                                    mask_out, ST_);
+}
+int instattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                      const float *loc, const float *spatial_w, const float *level_w, int B,
+                      int S, int H, int C, int L, int Lq, int P, uint16_t *out,
+                      uint16_t *mask_out, void *stream)
+{
+    return launch_fwd<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, DIMS, out,
+                                    mask_out, ST_);
+}
+
+int instattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *spatial_w, const float *level_w,
+                     const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
+                     int L, int Lq, int P, float *grad_value, float *grad_loc,
+                     float *grad_spatial_w, float *grad_level_w, void *stream)
+{
+    return launch_bwd<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
+                                   grad_mask, DIMS, grad_value, grad_loc, grad_spatial_w,
+                                   grad_level_w, grad_value, ST_);
+}
+int instattn_bwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                     const double *loc, const double *spatial_w, const double *level_w,
+                     const double *grad_out, const double *grad_mask, int B, int S, int H,
+                     int C, int L, int Lq, int P, double *grad_value, double *grad_loc,
+                     double *grad_spatial_w, double *grad_level_w, void *stream)
+{
+    return launch_bwd<double, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
+                                    grad_mask, DIMS, grad_value, grad_loc, grad_spatial_w,
+                                    grad_level_w, grad_value, ST_);
+}
+int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                      const float *loc, const float *spatial_w, const float *level_w,
+                      const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
+                      int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
+                      float *grad_spatial_w, float *grad_level_w, float *grad_value_ws,
+                      void *stream)
+{
+    return launch_bwd<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
+                                    grad_mask, DIMS, grad_value, grad_loc, grad_spatial_w,
+                                    grad_level_w, grad_value_ws, ST_);
+}
+
+}  // extern "C"

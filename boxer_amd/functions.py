@@ -1,0 +1,133 @@
+"""autograd Functions with the reference's signatures.
+
+``BoxAttnFunction`` / ``InstanceAttnFunction`` mirror
+e2edet/module/ops/box_attention_func.py:9-64 and :67-150 argument for argument:
+same positional inputs, same outputs, gradients only for value / sampling locations /
+attention weights (``None`` for the rest), ``once_differentiable``, and the same AMP
+contract (``custom_fwd(cast_inputs=torch.float32)``: under autocast every floating input
+is cast to float32 and the op runs with autocast disabled).
+
+``BoxAttnBF16Function`` / ``InstanceAttnBF16Function`` are the new native-bf16 mode
+(BASELINE.json configs[1]): ``value`` and the upstream gradients are bfloat16, locations and
+weights stay float32, accumulation is float32.  Same signatures otherwise.
+"""
+import torch
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+
+def _box_backward(ctx, grad_output):
+    if not grad_output.is_contiguous():
+        grad_output = grad_output.contiguous()
+    value, shapes, lsi, loc, attn = ctx.saved_tensors
+    grad_value, grad_loc, grad_attn = ops.box_attn_backward(
+        value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step)
+    return grad_value, None, None, grad_loc.to(ctx.loc_dtype), grad_attn.to(ctx.attn_dtype), None
+
+
+def _inst_backward(ctx, grad_output, grad_mask_output):
+    if not grad_output.is_contiguous():
+        grad_output = grad_output.contiguous()
+    if not grad_mask_output.is_contiguous():
+        grad_mask_output = grad_mask_output.contiguous()
+    value, shapes, lsi, loc, sw, lw = ctx.saved_tensors
+    grad_value, grad_loc, grad_sw, grad_lw = ops.instance_attn_backward(
+        value, shapes, lsi, loc, sw, lw, grad_output, grad_mask_output, ctx.im2col_step)
+    return (grad_value, None, None, grad_loc.to(ctx.loc_dtype), grad_sw.to(ctx.w_dtype),
+            grad_lw.to(ctx.w_dtype), None, None)
+
+
+class BoxAttnFunction(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.loc_dtype, ctx.attn_dtype = sampling_locations.dtype, attention_weights.dtype
+        output = ops.box_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                      sampling_locations, attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    @once_differentiable
+    def backward(ctx, grad_output):
+        return _box_backward(ctx, grad_output)
+
+
+class InstanceAttnFunction(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                spatial_attention_weights, level_attention_weights, mask_size, im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.loc_dtype, ctx.w_dtype = sampling_locations.dtype, spatial_attention_weights.dtype
+        output, mask_output = ops.instance_attn_forward(
+            value, value_spatial_shapes, value_level_start_index, sampling_locations,
+            spatial_attention_weights, level_attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, spatial_attention_weights,
+                              level_attention_weights)
+        b, l, _, c = mask_output.shape
+        return output, mask_output.view(b, l, mask_size, mask_size, c)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    @once_differentiable
+    def backward(ctx, grad_output, grad_mask_output):
+        return _inst_backward(ctx, grad_output, grad_mask_output)
+
+
+def _to_bf16_args(value, loc, *weights):
+    return (value.to(torch.bfloat16).contiguous(), loc.float().contiguous(),
+            *[w.float().contiguous() for w in weights])
+
+
+class BoxAttnBF16Function(Function):
+    """Native-bf16 flavour: output and grad_value are bfloat16, accumulation is float32."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.loc_dtype, ctx.attn_dtype = sampling_locations.dtype, attention_weights.dtype
+        ctx.value_dtype = value.dtype
+        value, loc, attn = _to_bf16_args(value, sampling_locations, attention_weights)
+        output = ops.box_attn_forward(value, value_spatial_shapes, value_level_start_index, loc,
+                                      attn, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        grads = _box_backward(ctx, grad_output.to(torch.bfloat16))
+        return (grads[0].to(ctx.value_dtype),) + grads[1:]
+
+
+class InstanceAttnBF16Function(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                spatial_attention_weights, level_attention_weights, mask_size, im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.loc_dtype, ctx.w_dtype = sampling_locations.dtype, spatial_attention_weights.dtype
+        ctx.value_dtype = value.dtype
+        value, loc, sw, lw = _to_bf16_args(value, sampling_locations, spatial_attention_weights,
+                                           level_attention_weights)
+        output, mask_output = ops.instance_attn_forward(
+            value, value_spatial_shapes, value_level_start_index, loc, sw, lw, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, sw, lw)
+        b, l, _, c = mask_output.shape
+        return output, mask_output.view(b, l, mask_size, mask_size, c)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output, grad_mask_output):
+        grads = _inst_backward(ctx, grad_output.to(torch.bfloat16),
+                               grad_mask_output.to(torch.bfloat16))
+        return (grads[0].to(ctx.value_dtype),) + grads[1:]

@@ -1,0 +1,153 @@
+"""``boxer_amd.ops`` -- drop-in for the reference's native module ``e2edet.ops``.
+
+Same four functions, same argument order and return values as the pybind module of the
+reference (e2edet/module/ops/src/vision.cpp:7-12; host code box_attn.cu:15-135,
+instance_attn.cu:15-157), implemented as thin calls into the C-ABI HIP library
+(include/boxattn.h).  Same error behaviour: CPU tensors raise "Not implemented on the CPU"
+(box_attn.h:53), non-contiguous tensors raise "... must be contiguous" (box_attn.cu:9-11),
+``batch % min(batch, im2col_step)`` is asserted (box_attn.cu:40-42).  Kernel launch errors
+raise instead of being printed (box_attn_kernel.cuh:1118-1122).
+
+Beyond the reference: ``value`` (and the upstream gradients) may be bfloat16; sampling
+locations and attention weights are then taken in float32 (bf16 ones are upcast) and all
+accumulation is float32.  float32 / float64 calls behave exactly like the reference.
+"""
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+
+
+def _check(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor: Not implemented on the CPU" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _prepare(value, shapes, lsi, loc, weights, extra=()):
+    """Validate like the reference's CHECK_INPUT block and derive the dimensions."""
+    _check(value, "value")
+    _check(shapes, "spatial_shapes")
+    _check(lsi, "level_start_index")
+    _check(loc, "sampling_loc")
+    for i, w in enumerate(weights):
+        _check(w, "attn_weight" if len(weights) == 1 else ("spatial_attn_weight", "level_attn_weight")[i])
+    for name, t in extra:
+        _check(t, name)
+    if value.dtype not in _SUFFIX:
+        raise RuntimeError("box_attn: unsupported dtype %s (float32, float64, bfloat16)" % value.dtype)
+    if shapes.dtype != torch.int64 or lsi.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    if value.dim() != 4 or loc.dim() != 6 or loc.size(-1) != 2:
+        raise RuntimeError("expected value (B,S,H,C) and sampling_loc (B,Lq,H,L,P,2)")
+    B, S, H, C = value.shape
+    L = shapes.size(0)
+    Lq, P = loc.size(1), loc.size(4)
+    if loc.size(0) != B or loc.size(2) != H or loc.size(3) != L or lsi.numel() != L:
+        raise RuntimeError("sampling_loc / spatial_shapes do not match value")
+    n_w = B * Lq * H * L * P
+    for w in weights:
+        if w.numel() != n_w:
+            raise RuntimeError("attention weights must have B*Lq*H*L*P elements")
+    cdt = torch.float32 if value.dtype == torch.bfloat16 else value.dtype
+    if value.dtype == torch.bfloat16:
+        loc = loc.float() if loc.dtype != torch.float32 else loc
+        weights = [w.float() if w.dtype != torch.float32 else w for w in weights]
+    elif loc.dtype != cdt or any(w.dtype != cdt for w in weights):
+        raise RuntimeError("value, sampling_loc and attention weights must share one dtype")
+    for name, t in extra:
+        if t.dtype != value.dtype:
+            raise RuntimeError("%s must have the dtype of value" % name)
+    return (B, S, H, C, L, Lq, P), loc, weights, cdt
+
+
+def _chunk_assert(batch, im2col_step):
+    step = min(batch, int(im2col_step))
+    if batch > 0:
+        assert step > 0 and batch % step == 0, \
+            "batch(%d) must divide im2col_step(%d)" % (batch, step)
+
+
+def _call(name, value, *args):
+    fn = getattr(_lib.load(), "%s_%s" % (name, _SUFFIX[value.dtype]))
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream(value.device).cuda_stream
+        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream)
+    if rc != 0:
+        raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
+
+
+def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                     im2col_step):
+    """-> output (B, Lq, H*C).  Reference: box_attn_cuda_forward (box_attn.cu:15-71)."""
+    dims, loc, (attn,), _ = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
+                                     [attn_weight])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
+    _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
+    return out
+
+
+def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                      grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (box_attn.cu:74-135).
+    For bfloat16 ``value`` the location / weight gradients are float32."""
+    dims, loc, (attn,), cdt = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
+                                       [attn_weight], [("grad_output", grad_output)])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    if grad_output.numel() != B * Lq * H * C:
+        raise RuntimeError("grad_output must have B*Lq*H*C elements")
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty(sampling_loc.shape, dtype=cdt, device=value.device)
+    grad_attn = torch.empty(attn_weight.shape, dtype=cdt, device=value.device)
+    args = [value, spatial_shapes, level_start_index, loc, attn, grad_output, *dims, grad_value,
+            grad_loc, grad_attn]
+    if value.dtype == torch.bfloat16:
+        args.append(torch.empty(value.shape, dtype=torch.float32, device=value.device))
+    _call("boxattn_bwd", value, *args)
+    return [grad_value, grad_loc, grad_attn]
+
+
+def instance_attn_forward(value, spatial_shapes, level_start_index, sampling_loc,
+                          spatial_attn_weight, level_attn_weight, im2col_step):
+    """-> [output (B,Lq,H*C), mask_output (B,Lq,P,H*C)] (instance_attn.cu:15-82)."""
+    dims, loc, (sw, lw), _ = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
+                                      [spatial_attn_weight, level_attn_weight])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
+    mask = torch.empty((B, Lq, P, H * C), dtype=value.dtype, device=value.device)
+    _call("instattn_fwd", value, value, spatial_shapes, level_start_index, loc, sw, lw, *dims,
+          out, mask)
+    return [out, mask]
+
+
+def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_loc,
+                           spatial_attn_weight, level_attn_weight, grad_output,
+                           grad_mask_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_spatial_attn_weight, grad_level_attn_weight]
+    (instance_attn.cu:85-157)."""
+    dims, loc, (sw, lw), cdt = _prepare(
+        value, spatial_shapes, level_start_index, sampling_loc,
+        [spatial_attn_weight, level_attn_weight],
+        [("grad_output", grad_output), ("grad_mask_output", grad_mask_output)])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    if grad_output.numel() != B * Lq * H * C or grad_mask_output.numel() != B * Lq * P * H * C:
+        raise RuntimeError("grad_output / grad_mask_output have the wrong number of elements")
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty(sampling_loc.shape, dtype=cdt, device=value.device)
+    grad_sw = torch.empty(spatial_attn_weight.shape, dtype=cdt, device=value.device)
+    grad_lw = torch.empty(level_attn_weight.shape, dtype=cdt, device=value.device)
+    args = [value, spatial_shapes, level_start_index, loc, sw, lw, grad_output, grad_mask_output,
+            *dims, grad_value, grad_loc, grad_sw, grad_lw]
+    if value.dtype == torch.bfloat16:
+        args.append(torch.empty(value.shape, dtype=torch.float32, device=value.device))
+    _call("instattn_bwd", value, *args)
+    return [grad_value, grad_loc, grad_sw, grad_lw]

@@ -1,0 +1,134 @@
+/*
+ * boxattn.h -- C ABI of the MI355X (gfx950) box-attention / instance-attention operator.
+ *
+ * This is the drop-in boundary for the one native component of kienduynguyen/BoxeR: the
+ * `e2edet.ops` extension with its four entry points (reference:
+ * e2edet/module/ops/src/vision.cpp:7-12).  Each group of functions below replaces one of
+ * them; the reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions (all functions):
+ *   - Every pointer is a DEVICE pointer on the current HIP device, including the int64
+ *     shape tables (the reference passes them as CUDA tensors, box_attn.cu:25-26).
+ *   - Tensors are dense, row-major, contiguous (reference CHECK_CONTIGUOUS, box_attn.cu:9-11):
+ *       value        (B, S, H, C)          S = sum_l H_l*W_l
+ *       shapes       (L, 2) int64          (H_l, W_l)
+ *       lsi          (L,)   int64          first row of level l inside S
+ *       loc          (B, Lq, H, L, P, 2)   normalised [0,1]; [..,0]=x (width), [..,1]=y
+ *       attn / spatial_w / level_w         (B, Lq, H, L, P)
+ *       out, grad_out                      (B, Lq, H, C)
+ *       mask_out, grad_mask                (B, Lq, P, H, C)
+ *   - Inputs are borrowed and never written.  Outputs are FULLY DEFINED by the call: the
+ *     functions zero-fill whatever they accumulate into (the reference relies on
+ *     at::zeros / zeros_like in its host code, box_attn.cu:44,105-107), so callers may pass
+ *     uninitialised memory.  Nothing is allocated or freed behind the ABI.
+ *   - `stream` is a hipStream_t (NULL = the default stream).  Calls are asynchronous.
+ *   - Return value: 0 on success, otherwise a hipError_t value (1 = hipErrorInvalidValue
+ *     for bad arguments).  Launch failures are returned, never just printed (the reference
+ *     only printf's them, box_attn_kernel.cuh:1118-1122).
+ *   - There is no `im2col_step`: in the reference it is pure batch chunking of the launch
+ *     (box_attn.cu:40-66) with no numerical effect.  One call covers the whole batch.
+ *
+ * Numeric types (suffix):
+ *   _f32   everything float32                      (the reference's training path)
+ *   _f64   everything float64                      (the reference's gradcheck path)
+ *   _bf16  value / out / mask_out / grad_out / grad_mask / grad_value are bfloat16;
+ *          loc, weights and their gradients stay float32; accumulation is float32.
+ *          (New: the reference raises on BFloat16, box_attn.cu:54.)  The backward needs a
+ *          float32 scratch of B*S*H*C elements for the grad_value accumulation.
+ */
+#ifndef BOXATTN_H_
+#define BOXATTN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI version of this header; bumped on any signature change. */
+#define BOXATTN_ABI_VERSION 1
+int boxattn_abi_version(void);
+
+/* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
+const char *boxattn_build_info(void);
+
+/* ---- replaces box_attn_forward (box_attn.h:29-54, box_attn.cu:15-71) ------------------ */
+int boxattn_fwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                    const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                    int Lq, int P, float *out, void *stream);
+int boxattn_fwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                    const double *loc, const double *attn, int B, int S, int H, int C, int L,
+                    int Lq, int P, double *out, void *stream);
+int boxattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                     int Lq, int P, uint16_t *out, void *stream);
+
+/* ---- replaces box_attn_backward (box_attn.h:56-83, box_attn.cu:74-135) ---------------- */
+int boxattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                    const float *loc, const float *attn, const float *grad_out, int B, int S,
+                    int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                    float *grad_attn, void *stream);
+int boxattn_bwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                    const double *loc, const double *attn, const double *grad_out, int B,
+                    int S, int H, int C, int L, int Lq, int P, double *grad_value,
+                    double *grad_loc, double *grad_attn, void *stream);
+/* grad_value_ws: float32 scratch, B*S*H*C elements, contents ignored and clobbered. */
+int boxattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *attn, const uint16_t *grad_out, int B,
+                     int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                     float *grad_loc, float *grad_attn, float *grad_value_ws, void *stream);
+
+/* ---- replaces instance_attn_forward (instance_attn.h:32-59, instance_attn.cu:15-82) --- */
+int instattn_fwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *spatial_w, const float *level_w, int B,
+                     int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
+                     void *stream);
+int instattn_fwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                     const double *loc, const double *spatial_w, const double *level_w, int B,
+                     int S, int H, int C, int L, int Lq, int P, double *out, double *mask_out,
+                     void *stream);
+int instattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                      const float *loc, const float *spatial_w, const float *level_w, int B,
+                      int S, int H, int C, int L, int Lq, int P, uint16_t *out,
+                      uint16_t *mask_out, void *stream);
+
+/* ---- replaces instance_attn_backward (instance_attn.h:61-92, instance_attn.cu:85-157) - */
+int instattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                     const float *loc, const float *spatial_w, const float *level_w,
+                     const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
+                     int L, int Lq, int P, float *grad_value, float *grad_loc,
+                     float *grad_spatial_w, float *grad_level_w, void *stream);
+int instattn_bwd_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                     const double *loc, const double *spatial_w, const double *level_w,
+                     const double *grad_out, const double *grad_mask, int B, int S, int H,
+                     int C, int L, int Lq, int P, double *grad_value, double *grad_loc,
+                     double *grad_spatial_w, double *grad_level_w, void *stream);
+int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                      const float *loc, const float *spatial_w, const float *level_w,
+                      const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
+                      int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
+                      float *grad_spatial_w, float *grad_level_w, float *grad_value_ws,
+                      void *stream);
+
+/*
+ * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):
+ *   0 = automatic choice (default), 1 = force the generic kernels (any C),
+ *   2.. = specific fast variants, see DESIGN.md.  Returns the previous value.
+ */
+int boxattn_set_variant(int variant);
+
+/*
+ * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the
+ * library brackets every launch of its main sampling kernels (forward kernel; backward
+ * kernel -- without the grad_value zero-fill and the bf16 conversion pass) with hipEvents
+ * recorded on the launch stream.  _end synchronises those events and returns the number of
+ * launches seen and their summed durations in milliseconds.  At most 4096 launches are kept.
+ */
+int boxattn_profile_begin(void);
+int boxattn_profile_end(double *fwd_ms_sum, int *fwd_launches, double *bwd_ms_sum,
+                        int *bwd_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXATTN_H_ */

@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports exactly what
+include/boxattn.h declares (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "boxattn.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:boxattn|instattn)_\w+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from boxer_amd import _lib
+    _lib.build()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_declares_the_four_entry_points_per_dtype():
+    names = declared_functions()
+    for stem in ("boxattn_fwd", "boxattn_bwd", "instattn_fwd", "instattn_bwd"):
+        for suf in ("f32", "f64", "bf16"):
+            assert "%s_%s" % (stem, suf) in names
+    assert "boxattn_abi_version" in names and "boxattn_set_variant" in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from boxer_amd import _lib
+    for name in declared_functions():
+        assert hasattr(lib, name), "missing export: " + name
+    assert sorted(_lib.EXPORTS) == declared_functions()
+
+
+def test_library_metadata(lib):
+    from boxer_amd import _lib
+    assert _lib.load().boxattn_abi_version() == 1
+    info = _lib.build_info()
+    assert "gfx950" in info
+    assert _lib.set_variant(1) == 0 and _lib.set_variant(0) == 1
+
+
+def test_library_contains_gfx950_code_object():
+    """The fat binary embedded in the .so carries a gfx950 code object (bundle entry id)."""
+    from boxer_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+
+
+def test_no_torch_types_in_the_abi():
+    code = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)      # strip comments
+    for banned in ("torch", "at::", "Tensor", "c10", "#include <ATen"):
+        assert banned not in code, banned
+    includes = re.findall(r"#include\s+[<\"]([^>\"]+)", code)
+    assert includes == ["stdint.h"]
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "boxer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "boxattn_oracle" not in src and "torch_fallback" not in src, f
