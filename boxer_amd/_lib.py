@@ -13,7 +13,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_NAME = "libboxattn_hip.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
 SOURCES = ["boxattn_capi.hip"]
-HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h"]
+HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h", "boxattn_binned.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared", "-Wall", "-Wno-pass-failed"]
 
@@ -28,9 +28,16 @@ _SIGNATURES = {
     "instattn_fwd": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp],
     "instattn_bwd": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp],
 }
+_WS_SIGNATURES = {
+    # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, stream
+    "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _vp],
+}
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
-           "boxattn_profile_begin", "boxattn_profile_end"] + [
-    "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")]
+           "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes"] + [
+    "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
+    "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
+ABI_VERSION = 2
 
 
 def hipcc_path():
@@ -85,7 +92,14 @@ def load():
             extra = [_vp] if (suf == "bf16" and stem.endswith("bwd")) else []
             fn.argtypes = args[:-1] + extra + args[-1:]        # ..., [grad_value_ws], stream
             fn.restype = _i
-    if lib.boxattn_abi_version() != 1:
+    for stem, args in _WS_SIGNATURES.items():
+        for suf in ("f32", "bf16"):
+            fn = getattr(lib, "%s_%s" % (stem, suf))
+            fn.argtypes = args
+            fn.restype = _i
+    lib.boxattn_bwd_workspace_bytes.argtypes = [_i] * 8 + [_vp, _vp]
+    lib.boxattn_bwd_workspace_bytes.restype = ctypes.c_size_t
+    if lib.boxattn_abi_version() != ABI_VERSION:
         raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib
@@ -96,7 +110,8 @@ def build_info():
 
 
 def set_variant(v):
-    """0 = auto, 1 = generic kernels only, 2 = fast kernels only (error if not eligible)."""
+    """0 = auto, 1 = generic kernels only, 2 = fast atomic kernels only, 3 = binned backward
+    only (2 and 3 return an error when the shape is not eligible)."""
     return load().boxattn_set_variant(int(v))
 
 

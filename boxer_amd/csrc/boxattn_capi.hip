@@ -12,6 +12,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "boxattn_binned.h"
 #include "boxattn_fast.h"
 #include "boxattn_generic.h"
 
@@ -19,7 +20,9 @@ using namespace boxattn;
 
 namespace {
 
-int g_variant = 0;   // 0 auto, 1 generic only, 2 fast (fails if the shape does not qualify)
+// 0 auto | 1 generic kernels only | 2 fast atomic kernels (error if the shape does not qualify,
+// never the binned backward) | 3 binned backward required (error if not eligible)
+int g_variant = 0;
 
 inline int ceil_div_sz(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 
@@ -242,16 +245,256 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     return 0;
 }
 
+
+// ------------------------------------------------------- binned backward (boxattn_binned.h)
+constexpr int kChunk = 1024;          // records per work item
+constexpr int kMaxBlocks = 8192;      // per (image, head) slice: 2 LDS ints each in bin_kernel
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct WsLayout {
+    size_t counts, cursors, qhead, n_items, zero_bytes;     // [0, zero_bytes) is memset to 0
+    size_t offsets, items, records, gv_acc, total;
+};
+
+template <int G> bool make_plan_g(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
+{
+    constexpr int BW = BlockShape<G>::W, BH = BlockShape<G>::H;
+    p.L = d.L;
+    long long blk0 = 0, next_start = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1], st = ls[l];
+        // standard packed layout only: level l starts where level l-1 ends (every grad_value
+        // row then has exactly one owner block)
+        if (hl < 0 || wl < 0 || hl > INT32_MAX || wl > INT32_MAX || st != next_start ||
+            st + hl * wl > d.S)
+            return false;
+        next_start = st + hl * wl;
+        p.lv[l].H = (int)hl;
+        p.lv[l].W = (int)wl;
+        p.lv[l].start = (int)st;
+        p.lv[l].nbx = (int)((wl + BW - 1) / BW);
+        p.lv[l].nby = (int)((hl + BH - 1) / BH);
+        p.lv[l].blk0 = (int)blk0;
+        blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
+    }
+    const long long rec_cap = 4ll * d.Lq * d.L * d.P;
+    if (blk0 == 0 || blk0 > kMaxBlocks || rec_cap > INT32_MAX / 2 ||
+        (long long)d.B * d.Lq * d.H > INT32_MAX || (long long)d.B * d.Lq * d.P * d.H > INT32_MAX)
+        return false;
+    p.nblk = (int)blk0;
+    p.rec_cap = (int)rec_cap;
+    p.chunk = kChunk;
+    p.item_cap = (int)(blk0 + rec_cap / kChunk + 1);
+    return true;
+}
+
+inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
+{
+    if (!sh || !ls || !d.valid() || fast_group(d) == 0) return false;
+    switch (fast_group(d)) {
+        case 4: return make_plan_g<4>(d, sh, ls, p);
+        case 8: return make_plan_g<8>(d, sh, ls, p);
+        case 16: return make_plan_g<16>(d, sh, ls, p);
+    }
+    return false;
+}
+
+inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
+{
+    const size_t ns = (size_t)d.B * d.H;
+    WsLayout w;
+    size_t o = 0;
+    w.counts = o;  o += align_up(ns * p.nblk * 4);
+    w.cursors = o; o += align_up(ns * p.nblk * 4);
+    w.qhead = o;   o += align_up(ns * 4);
+    w.n_items = o; o += align_up(ns * 4);
+    w.zero_bytes = o;
+    w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
+    w.items = o;   o += align_up(ns * p.item_cap * 16);
+    w.records = o; o += align_up(ns * (size_t)p.rec_cap * 4);
+    w.gv_acc = o;  o += need_gv_acc ? align_up(d.n_value() * 4) : 0;
+    w.total = o;
+    return w;
+}
+
+template <typename ST, int G, bool INST>
+int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+               const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
+               const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, float *gv_acc,
+               float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
+{
+    constexpr int BW = BlockShape<G>::W, BH = BlockShape<G>::H;
+    const int ns = d.B * d.H;
+    int *counts = (int *)(ws + w.counts), *cursors = (int *)(ws + w.cursors);
+    int *qhead = (int *)(ws + w.qhead), *n_items = (int *)(ws + w.n_items);
+    int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
+    int4 *items = (int4 *)(ws + w.items);
+    hipError_t e = hipMemsetAsync(ws, 0, w.zero_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    // ~2048 workgroups for the two binning passes
+    const int q_per_wg = std::max(8, (int)(((long long)d.Lq * ns + 2047) / 2048));
+    const dim3 bgrid((d.Lq + q_per_wg - 1) / q_per_wg, ns);
+    const size_t bsh = (size_t)plan.nblk * 2 * sizeof(int);
+    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
+                       d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, counts, offsets, items,
+                       n_items, plan);
+    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
+                       d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+    {   // grad_loc / grad_weight, query-major, no scatter
+        ScopedKernelTimer timer(g_prof.bwd, st);
+        const size_t n_qh = d.n_qh();
+        const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
+        hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256), 0,
+                           st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S,
+                           d.H, d.L, d.Lq, d.P, gv_acc, grad_loc, grad_sp, grad_lv, n_qh);
+    }
+    const int wg_per_slice = std::max(1, 2048 / ns);
+    hipLaunchKernelGGL((binned_accumulate_kernel<ST, G, INST>), dim3(wg_per_slice, ns), dim3(256),
+                       0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
+                       offsets, items, n_items, qhead, records, gv_acc);
+    return finish();
+}
+
+// Backward with a caller-provided workspace; falls back to the atomic kernels when the
+// binned algorithm does not apply.
+template <typename ST, bool INST>
+int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                  const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
+                  const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
+                  const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                  size_t workspace_bytes, hipStream_t st)
+{
+    constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
+    if (!d.valid()) return (int)hipErrorInvalidValue;
+    BinPlan plan;
+    const size_t nv = d.n_value();
+    bool binned = (g_variant == 0 || g_variant == 3) && workspace && nv && d.n_qh() &&
+                  make_plan(d, shapes_host, lsi_host, plan) &&
+                  fast_ok<ST>(d, value, loc, grad_out,
+                              INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
+                  aligned(workspace, 256) && aligned(grad_value, 16);
+    WsLayout w{};
+    if (binned) {
+        w = ws_layout(d, plan, kBf16);
+        binned = workspace_bytes >= w.total;
+    }
+    if (!binned) {
+        if (g_variant == 3) return (int)hipErrorInvalidValue;
+        float *acc = nullptr;
+        if constexpr (kBf16) {
+            if (!workspace || workspace_bytes < nv * sizeof(float)) return (int)hipErrorInvalidValue;
+            acc = (float *)workspace;
+        } else {
+            acc = grad_value;
+        }
+        return launch_bwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d,
+                                    grad_value, grad_loc, grad_sp, grad_lv, acc, st);
+    }
+    if (!shapes || !lsi || !loc || !w_sp || !grad_out || !grad_loc || !grad_sp || !grad_value ||
+        !value || (INST && (!w_lv || !grad_mask || !grad_lv)))
+        return (int)hipErrorInvalidValue;
+    char *ws = (char *)workspace;
+    float *gv_acc;
+    if constexpr (kBf16) gv_acc = (float *)(ws + w.gv_acc);
+    else gv_acc = grad_value;
+    hipError_t e = hipMemsetAsync(gv_acc, 0, nv * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    int rc = 0;
+    switch (fast_group(d)) {
+#define BOXATTN_BINNED_CASE(GG)                                                                 \
+    case GG:                                                                                    \
+        rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
+                                      d, plan, w, ws, gv_acc, grad_loc, grad_sp, grad_lv, st);  \
+        break;
+        BOXATTN_BINNED_CASE(4)
+        BOXATTN_BINNED_CASE(8)
+        BOXATTN_BINNED_CASE(16)
+#undef BOXATTN_BINNED_CASE
+    }
+    if (rc) return rc;
+    if constexpr (kBf16) {
+        const int blocks = (int)std::min<size_t>((nv / 4 + 255) / 256 + 1, 256 * 16);
+        hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, gv_acc,
+                           grad_value, nv);
+        return finish();
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
+                                   const int64_t *shapes_host, const int64_t *lsi_host)
+{
+    const Dims d{B, S, H, C, L, Lq, P};
+    if (!d.valid()) return 0;
+    const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
+    BinPlan plan;
+    if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
+    return std::max(fallback, ws_layout(d, plan, is_bf16 != 0).total);
+}
+
+int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *loc, const float *attn, const float *grad_out, int B, int S,
+                       int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                       float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
+                                       Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
+                                       grad_attn, nullptr, shapes_host, lsi_host, workspace,
+                                       workspace_bytes, (hipStream_t)stream);
+}
+int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *attn, const uint16_t *grad_out, int B,
+                        int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                        float *grad_loc, float *grad_attn, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
+                                        Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
+                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
+                                        workspace_bytes, (hipStream_t)stream);
+}
+int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *spatial_w, const float *level_w,
+                        const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
+                        int L, int Lq, int P, float *grad_value, float *grad_loc,
+                        float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
+                                      grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
+                                      grad_spatial_w, grad_level_w, shapes_host, lsi_host,
+                                      workspace, workspace_bytes, (hipStream_t)stream);
+}
+int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *spatial_w, const float *level_w,
+                         const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
+                         int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
+                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
+                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                         void *stream)
+{
+    return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
+                                       grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
+                                       grad_spatial_w, grad_level_w, shapes_host, lsi_host,
+                                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 
 int boxattn_abi_version(void) { return BOXATTN_ABI_VERSION; }
 
 const char *boxattn_build_info(void)
 {
     return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
-           " | kernels: generic{f32,f64,bf16}, fast{f32,bf16} VEC=4 G={4,8,16}";
+           " | kernels: generic{f32,f64,bf16}, fast{f32,bf16} VEC=4 G={4,8,16}, binned-bwd{f32,bf16}";
 }
 
 int boxattn_profile_begin(void)

@@ -102,6 +102,7 @@ template <typename T> struct Sample {
                      // the map so it is always safe to load from; use ok[] to discard
     bool ok[4];      // corner lies inside the map
     bool inside;     // passes the reference window test
+    int y0, x0;      // unclamped top-left corner (floor of the pixel coordinate), >= -1
 };
 
 template <typename T>
@@ -118,6 +119,8 @@ __device__ __forceinline__ Sample<T> locate(T x, T y, int Hl, int Wl) {
     const T ws = s.inside ? w_im : (T)0;
     const T hf = floor(hs), wf = floor(ws);
     const int h_low = (int)hf, w_low = (int)wf;
+    s.y0 = h_low;
+    s.x0 = w_low;
     s.lh = hs - hf;
     s.lw = ws - wf;
     s.hh = (T)1 - s.lh;

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void fwd_fast_kernel(
 // ---------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------
-template <typename ST, int VEC, int G, bool INST>
+// SCATTER = false turns the kernel into the "point gradients" half of the binned backward
+// (grad_loc / grad_weight only; grad_value comes from boxattn_binned.h without atomics).
+template <typename ST, int VEC, int G, bool INST, bool SCATTER = true>
 __global__ __launch_bounds__(256) void bwd_fast_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void bwd_fast_kernel(
                 px += dw * t[c];
                 py += dh * t[c];
             }
-            if (active) {
+            if (SCATTER && active) {
                 if (s.ok[0]) {
                     float *d = gvl + (size_t)s.pix[0] * HC;
 #pragma unroll

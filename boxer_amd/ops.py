@@ -72,6 +72,38 @@ def _chunk_assert(batch, im2col_step):
             "batch(%d) must divide im2col_step(%d)" % (batch, step)
 
 
+_HOST_TABLES = {}          # (data_ptr, version, numel, device) -> numpy int64 copy
+
+
+def _host_table(t):
+    """Host copy of a small int64 device table (level shapes / start indices), cached per
+    tensor so that only the first call with a given tensor synchronises."""
+    key = (t.data_ptr(), t._version, t.numel(), t.device.index)
+    got = _HOST_TABLES.get(key)
+    if got is None:
+        if len(_HOST_TABLES) > 64:
+            _HOST_TABLES.clear()
+        got = t.detach().cpu().contiguous().numpy().copy()
+        _HOST_TABLES[key] = got
+    return got
+
+
+def _backward_with_workspace(name, value, shapes, lsi, dims, args):
+    """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
+    lib = _lib.load()
+    sh, ls = _host_table(shapes), _host_table(lsi)
+    is_bf16 = int(value.dtype == torch.bfloat16)
+    nbytes = lib.boxattn_bwd_workspace_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=value.device)
+    fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream(value.device).cuda_stream
+        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
+                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(), stream)
+    if rc != 0:
+        raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
+
+
 def _call(name, value, *args):
     fn = getattr(_lib.load(), "%s_%s" % (name, _SUFFIX[value.dtype]))
     with torch.cuda.device(value.device):
@@ -108,9 +140,11 @@ def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, at
     grad_attn = torch.empty(attn_weight.shape, dtype=cdt, device=value.device)
     args = [value, spatial_shapes, level_start_index, loc, attn, grad_output, *dims, grad_value,
             grad_loc, grad_attn]
-    if value.dtype == torch.bfloat16:
-        args.append(torch.empty(value.shape, dtype=torch.float32, device=value.device))
-    _call("boxattn_bwd", value, *args)
+    if value.dtype == torch.float64:
+        _call("boxattn_bwd", value, *args)
+    else:
+        _backward_with_workspace("boxattn_bwd_ws", value, spatial_shapes, level_start_index,
+                                 dims, args)
     return [grad_value, grad_loc, grad_attn]
 
 
@@ -147,7 +181,9 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
     grad_lw = torch.empty(level_attn_weight.shape, dtype=cdt, device=value.device)
     args = [value, spatial_shapes, level_start_index, loc, sw, lw, grad_output, grad_mask_output,
             *dims, grad_value, grad_loc, grad_sw, grad_lw]
-    if value.dtype == torch.bfloat16:
-        args.append(torch.empty(value.shape, dtype=torch.float32, device=value.device))
-    _call("instattn_bwd", value, *args)
+    if value.dtype == torch.float64:
+        _call("instattn_bwd", value, *args)
+    else:
+        _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index,
+                                 dims, args)
     return [grad_value, grad_loc, grad_sw, grad_lw]

@@ -39,6 +39,7 @@
 #ifndef BOXATTN_H_
 #define BOXATTN_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 1
+#define BOXATTN_ABI_VERSION 2
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -111,9 +112,51 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
                       void *stream);
 
 /*
+ * ---- backward with a caller-provided workspace (the fast path) ---------------------------
+ * Same contract as the plain backward entry points above, plus:
+ *   shapes_host / lsi_host : HOST copies of the two int64 level tables (the reference keeps
+ *       them only on the device; the binding caches a host copy per tensor).  They let the
+ *       library plan the destination-binned algorithm without a
+ *       device->host sync.  May be NULL: the call then behaves like the plain backward.
+ *   workspace / workspace_bytes : device scratch, 256-byte aligned, contents ignored and
+ *       clobbered; size from boxattn_bwd_workspace_bytes() (covers the bf16 fp32 scratch too).
+ * If the shape is not eligible or the workspace is too small, the call falls back to the
+ * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
+ * B*S*H*C floats).  Only float32 and bfloat16 exist here; float64 uses the plain backward.
+ */
+size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
+                                   const int64_t *shapes_host, const int64_t *lsi_host);
+int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *loc, const float *attn, const float *grad_out, int B, int S,
+                       int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                       float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *attn, const uint16_t *grad_out, int B,
+                        int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                        float *grad_loc, float *grad_attn, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *spatial_w, const float *level_w,
+                        const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
+                        int L, int Lq, int P, float *grad_value, float *grad_loc,
+                        float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *spatial_w, const float *level_w,
+                         const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
+                         int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
+                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
+                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/*
  * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):
  *   0 = automatic choice (default), 1 = force the generic kernels (any C),
- *   2.. = specific fast variants, see DESIGN.md.  Returns the previous value.
+ *   2 = fast atomic kernels (error if the shape does not qualify; never the binned backward),
+ *   3 = binned backward required (error if not eligible).  Returns the previous value.
  */
 int boxattn_set_variant(int variant);
 

@@ -40,7 +40,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_library_metadata(lib):
     from boxer_amd import _lib
-    assert _lib.load().boxattn_abi_version() == 1
+    declared = int(re.search(r"#define BOXATTN_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert _lib.load().boxattn_abi_version() == declared == _lib.ABI_VERSION
     info = _lib.build_info()
     assert "gfx950" in info
     assert _lib.set_variant(1) == 0 and _lib.set_variant(0) == 1

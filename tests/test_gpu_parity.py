@@ -17,7 +17,7 @@ from oracle import boxattn_oracle as oc
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 1e-2}
-VARIANTS = {"auto": 0, "generic": 1}
+VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3}
 
 
 def dev(a, dtype=None):
@@ -191,6 +191,54 @@ def test_instance_vs_oracle(cfg, dtype):
     close(gl, want[1], torch.float32, "grad_loc")
     close(gs, want[2], torch.float32, "grad_spatial")
     close(glw, want[3], torch.float32, "grad_level")
+
+
+# every backward algorithm of the fast family on the BoxeR geometry (C = 16 / 32 / 64):
+# "atomic" = hardware fp atomics per contribution, "binned" = destination-binned, no atomics
+FAST_CFGS = [SEEDED[0], SEEDED[1], SEEDED[2], SEEDED[3],
+             ([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4),   # several blocks / level
+             ([(16, 24)], 1, 8, 32, 3000, 4)]                              # chunked heavy bins
+
+
+@pytest.mark.parametrize("variant", ["atomic", "binned"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", FAST_CFGS, ids=[str(i) for i in range(len(FAST_CFGS))])
+def test_box_backward_algorithms(cfg, dtype, variant):
+    g = _seeded(*cfg, seed=21, lo=-0.2, hi=1.2)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    out, gv, gl, ga = run_box(g, dtype, variant)
+    close(gv, want[0], dtype, "grad_value")
+    close(gl, want[1], torch.float32, "grad_loc")
+    close(ga, want[2], torch.float32, "grad_attn")
+
+
+@pytest.mark.parametrize("variant", ["atomic", "binned"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", FAST_CFGS[:5], ids=[str(i) for i in range(5)])
+def test_instance_backward_algorithms(cfg, dtype, variant):
+    g = _seeded(*cfg, seed=22, lo=-0.2, hi=1.2)
+    want = oc.instance_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"],
+                                     g["spatial_w"], g["level_w"], g["grad_out"],
+                                     g["grad_mask"])
+    out, mask, gv, gl, gs, glw = run_inst(g, dtype, variant)
+    close(gv, want[0], dtype, "grad_value")
+    close(gl, want[1], torch.float32, "grad_loc")
+    close(gs, want[2], torch.float32, "grad_spatial")
+    close(glw, want[3], torch.float32, "grad_level")
+
+
+def test_binned_backward_clustered_points():
+    """All sample points of a head on one pixel: one bin gets every record (many chunks),
+    all other bins are empty."""
+    g = _seeded([(12, 20), (6, 10)], 2, 8, 32, 500, 4, seed=23)
+    g["loc"][...] = 0.5 + (g["loc"] - 0.5) * 1e-3
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    out, gv, gl, ga = run_box(g, torch.float32, "binned")
+    close(gv, want[0], torch.float32, "grad_value")
+    close(gl, want[1], torch.float32, "grad_loc")
+    close(ga, want[2], torch.float32, "grad_attn")
 
 
 # ------------------------------------------------------------------ edge cases
