@@ -25,10 +25,14 @@ def dev(a, dtype=None):
     return t.to(dtype) if dtype is not None else t
 
 
-def close(got, want, dtype, what):
+def close(got, want, dtype, what, ignore=None):
+    """``ignore``: boolean mask (broadcastable to ``want``) of entries excluded from the check."""
     got = got.detach().double().cpu().numpy()
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, (what, got.shape, want.shape)
+    if ignore is not None:
+        keep = ~np.broadcast_to(ignore, want.shape)
+        got, want = got * keep, want * keep
     scale = max(1.0, float(np.abs(want).max()) if want.size else 1.0)
     err = float(np.abs(got - want).max()) / scale if want.size else 0.0
     assert err <= TOL[dtype], "%s: max scaled err %.3e > %.1e" % (what, err, TOL[dtype])
@@ -147,7 +151,17 @@ def _seeded(shapes, B, H, C, Lq, P, seed, lo=-0.1, hi=1.1):
     gout = rng.integers(-64, 65, (B, Lq, H * C)).astype(np.float64) / 32
     gmask = rng.integers(-64, 65, (B, Lq, P, H * C)).astype(np.float64) / 32
     return dict(value=value, shapes=shapes, lsi=lsi, loc=loc, attn=attn, spatial_w=attn,
-                level_w=lvl, grad_out=gout, grad_mask=gmask)
+                level_w=lvl, grad_out=gout, grad_mask=gmask, on_edge=on_cell_edge(loc, shapes))
+
+
+def on_cell_edge(loc, shapes, eps=1e-4):
+    """(B,Lq,H,L,P,1) mask of points whose pixel coordinate is within eps of an integer.
+    grad_loc is discontinuous there (the bilinear cell changes), so float32 arithmetic and the
+    float64 oracle may legitimately pick different cells; such points are excluded from the
+    grad_loc comparison (their other outputs are continuous and stay checked)."""
+    size = np.asarray(shapes, dtype=np.float64)[None, None, None, :, None, ::-1]   # (W, H)
+    pix = loc * size - 0.5
+    return (np.abs(pix - np.round(pix)) < eps).any(-1, keepdims=True)
 
 
 SEEDED = [
@@ -171,7 +185,7 @@ def test_box_vs_oracle(cfg, dtype):
     out, gv, gl, ga = run_box(g, dtype, "auto")
     close(out, want_out, dtype, "out")
     close(gv, want[0], dtype, "grad_value")
-    close(gl, want[1], torch.float32, "grad_loc")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
     close(ga, want[2], torch.float32, "grad_attn")
 
 
@@ -188,7 +202,7 @@ def test_instance_vs_oracle(cfg, dtype):
     close(out, want_out, dtype, "out")
     close(mask, want_mask, dtype, "mask_out")
     close(gv, want[0], dtype, "grad_value")
-    close(gl, want[1], torch.float32, "grad_loc")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
     close(gs, want[2], torch.float32, "grad_spatial")
     close(glw, want[3], torch.float32, "grad_level")
 
@@ -209,7 +223,7 @@ def test_box_backward_algorithms(cfg, dtype, variant):
                                 g["grad_out"])
     out, gv, gl, ga = run_box(g, dtype, variant)
     close(gv, want[0], dtype, "grad_value")
-    close(gl, want[1], torch.float32, "grad_loc")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
     close(ga, want[2], torch.float32, "grad_attn")
 
 
@@ -223,7 +237,7 @@ def test_instance_backward_algorithms(cfg, dtype, variant):
                                      g["grad_mask"])
     out, mask, gv, gl, gs, glw = run_inst(g, dtype, variant)
     close(gv, want[0], dtype, "grad_value")
-    close(gl, want[1], torch.float32, "grad_loc")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
     close(gs, want[2], torch.float32, "grad_spatial")
     close(glw, want[3], torch.float32, "grad_level")
 
@@ -237,7 +251,7 @@ def test_binned_backward_clustered_points():
                                 g["grad_out"])
     out, gv, gl, ga = run_box(g, torch.float32, "binned")
     close(gv, want[0], torch.float32, "grad_value")
-    close(gl, want[1], torch.float32, "grad_loc")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
     close(ga, want[2], torch.float32, "grad_attn")
 
 
