@@ -15,16 +15,18 @@
 //                          the work-item list (blocks with many points are cut into chunks).
 //   3. bin_kernel<fill>    same pass again, now writing the point ids into their bins.
 //   4. bwd_fast_kernel<SCATTER=false> (boxattn_fast.h): grad_loc / grad_weight, query-major.
-//   5. binned_accumulate_kernel  one workgroup per work item: records -> geometry ->
+//   5. binned_accumulate_kernel  one wavefront per work item: records -> geometry ->
 //                          per-pixel entry lists in LDS (integer LDS atomics for the ranks);
-//                          the records' upstream-gradient rows (times the attention weight)
-//                          are staged once in LDS; each 8-lane group owns one destination
-//                          pixel and sums w * row over its list in registers; one plain
-//                          coalesced 128-byte row store per pixel (fp32 atomics only for the
-//                          few blocks that were cut into chunks, i.e. the coarse levels).
+//                          the records' upstream-gradient rows are staged once in LDS; each
+//                          lane pair owns one destination pixel and sums (w*a) * row over its
+//                          list in registers; one plain coalesced row store per pixel (fp32
+//                          atomics only for the few blocks that were cut into chunks, i.e.
+//                          the coarse levels).
 //
 // The result is the same sum as the reference's, in a different (still unspecified) order.
 #pragma once
+#include <type_traits>
+
 #include "boxattn_device.h"
 
 namespace boxattn {
@@ -41,13 +43,9 @@ struct BinPlan {
     int rec_cap;          // record capacity per slice (worst case: every point in 4 blocks)
     int item_cap;         // work-item capacity per slice
     int chunk;            // records per work item
+    int lp_bits;          // record = (query << lp_bits) | (level*P + point)
     BinLevel lv[kMaxLevels];
 };
-
-template <int G> struct BlockShape;             // G lanes per pixel -> 256/G pixels per block
-template <> struct BlockShape<4>  { static constexpr int W = 8, H = 8; };
-template <> struct BlockShape<8>  { static constexpr int W = 8, H = 4; };
-template <> struct BlockShape<16> { static constexpr int W = 4, H = 4; };
 
 // Blocks touched by the (valid part of the) 2x2 footprint of a sample; at most 2x2.
 template <int BW, int BH>
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc,
         const int n = touched_blocks<BW, BH>(sm, plan.lv[l], blk);
         for (int j = 0; j < n; ++j) {
             const int slot = base[blk[j]] + atomicAdd(&hist[blk[j]], 1);
-            rec[slot] = q * LP + lp;                     // point id inside the slice
+            rec[slot] = (q << plan.lp_bits) | lp;        // point id inside the slice
         }
     }
 }
@@ -174,146 +172,254 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(const int *__restrict__ c
 }
 
 // ---------------------------------------------------------------------------------------
-// 5: accumulate.  grid = (workgroups per slice, slices), block 256; persistent over items.
+// 5: accumulate.  One WAVEFRONT per work item (64-thread workgroups, no cross-wave barriers):
+//    every wave has private LDS and runs independently, so the many dependent latencies of an
+//    item (record id -> location / weight -> upstream-gradient row) are hidden by the other
+//    ~12 waves of the CU instead of stalling a 256-thread workgroup at barriers.
+//    grid = (waves per slice, slices); waves are persistent and pull items from the slice's
+//    queue.  A block is 8x4 pixels; in the summation phase lane = (pixel, channel half).
 // ---------------------------------------------------------------------------------------
-template <typename ST, int G, bool INST>
-__global__ __launch_bounds__(256) void binned_accumulate_kernel(
+template <typename ST, int C, bool INST>
+__global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask,
     const float *__restrict__ loc, const float *__restrict__ w_sp,
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
     const int *__restrict__ offsets, const int4 *__restrict__ items,
     const int *__restrict__ n_items, int *__restrict__ qhead, const int *__restrict__ records,
-    float *__restrict__ grad_value)
+    float *__restrict__ grad_value, int dbg)
 {
-    constexpr int VEC = 4, C = VEC * G, PB = 256 / G;
-    constexpr int BW = BlockShape<G>::W, BH = BlockShape<G>::H;
-    constexpr int R = (G == 16) ? 128 : 256;          // records per round
-    constexpr int TS = C + 4;                         // padded row stride (floats), 16-B aligned
-    __shared__ __attribute__((aligned(16))) float tstage[R * TS];
-    __shared__ float2 ent[4 * R];                     // {bilinear weight, record slot}
-    __shared__ int pcnt[64], poff[65];
-    __shared__ int rec_row[R], rec_mrow[INST ? R : 1];
-    __shared__ float rec_as[R], rec_al[INST ? R : 1];
-    __shared__ int cur_item;
+    constexpr int BW = 8, BH = 4, PB = 32, R = 64;
+    constexpr int CH = C / 2;                          // channels per lane while summing
+    constexpr int ROWB = C * (int)sizeof(ST);          // bytes of one upstream-gradient row
+    constexpr int RS = ROWB + 16;                      // padded LDS row stride (bank spread)
+    constexpr int LPR = ROWB / 16;                     // lanes that stage one row, 16 B each
+    constexpr int RPP = 64 / LPR;                      // rows staged per pass
+    constexpr int NPASS = R / RPP;                     // staging passes per round
+    constexpr int EPL = 16 / (int)sizeof(ST);          // elements per 16-byte piece
+    constexpr int UNR = 2;                             // list entries handled per step
+    typedef typename std::conditional<INST, float4, float2>::type Entry;   // {w*a_s[, w*a_l], j}
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector: stays in VGPRs
+    // row R of the stages is all zeros: the target of padded (unused) list entries
+    __shared__ __attribute__((aligned(16))) unsigned char gstage[(R + 1) * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char mstage[INST ? (R + 1) * RS : 16];
+    __shared__ __attribute__((aligned(16))) Entry ent[4 * R + UNR + 1];    // [4R+UNR] = dump slot
+    __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
 
     const int s = blockIdx.y, b = s / H, h = s % H;
     const int LP = plan.L * P;
-    const int tid = threadIdx.x, m = tid % G, mypix = tid / G;
+    const int lane = threadIdx.x;
+    const int mypix = lane >> 1, half = lane & 1;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     const int n_it = n_items[s];
+    const int lp_mask = (1 << plan.lp_bits) - 1;
 
-    for (;;) {
-        if (tid == 0) cur_item = atomicAdd(&qhead[s], 1);
-        __syncthreads();
-        const int it = cur_item;
-        if (it >= n_it) break;
-        const int4 item = items[(size_t)s * plan.item_cap + it];
+    for (int i = lane; i < RS / 4; i += 64) {          // the zero rows
+        reinterpret_cast<int *>(&gstage[R * RS])[i] = 0;
+        if constexpr (INST) reinterpret_cast<int *>(&mstage[R * RS])[i] = 0;
+    }
+
+    // Static round-robin over the slice's items (heaviest first): no work-queue atomics -- a
+    // shared queue head is one cache line that every wave of the chip hammers (measured:
+    // ~13 k dequeues on one line cost 160 us, more than the useful work).
+    for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
+        // coarse levels sit at the end of the list and carry the long chunked items: take
+        // them first so the tail of the kernel is made of short items
+        const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];
         const int blk = item.x;
-        int l = 0;
-        while (l + 1 < plan.L && blk >= plan.lv[l + 1].blk0) ++l;
-        const BinLevel lv = plan.lv[l];
+        BinLevel lv = plan.lv[0];                    // select, no dynamic indexing of kernel args
+#pragma unroll
+        for (int k = 1; k < kMaxLevels; ++k)
+            if (k < plan.L && blk >= plan.lv[k].blk0) lv = plan.lv[k];
         const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
         const int oy = by * BH, ox = bx * BW;
         const int *rec = records + (size_t)s * plan.rec_cap +
                          offsets[(size_t)s * (plan.nblk + 1) + blk];
-        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+        float acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
 
+        // Software pipeline over rounds of R records: everything global that round r+1 needs
+        // (record ids, locations, weights, upstream-gradient rows) is issued at the top of
+        // round r and consumed one iteration later.  Inactive lanes use record 0 (valid).
+        auto fetch_ids = [&](int rr) -> int {
+            return (rr + lane < item.z) ? rec[rr + lane] : 0;
+        };
+        int row_n = 0, mr_n = 0;                       // rows of the round being fetched
+        auto fetch_point = [&](int r, float2 &xy, float &as, float &al) {
+            const int q = r >> plan.lp_bits, lp = r & lp_mask;
+            row_n = (int)(((size_t)b * Lq + q) * H + h);
+            const size_t pid = (size_t)row_n * LP + lp;
+            xy = loc2[pid];
+            as = w_sp[pid];
+            al = INST ? w_lv[pid] : 0.f;
+            mr_n = INST ? (int)((((size_t)b * Lq + q) * P + lp % P) * H + h) : 0;
+        };
+        u32x4 grow[NPASS], mrow[INST ? NPASS : 1];     // rows in flight (registers)
+#define BOXATTN_FETCH_ROWS()                                                                    \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
+        const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
+        const int rj_ = __shfl(row_n, j_, 64);                                                  \
+        grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj_ * C + piece_ * EPL); \
+        if constexpr (INST) {                                                                   \
+            const int mj_ = __shfl(mr_n, j_, 64);                                               \
+            mrow[ps] =                                                                          \
+                *reinterpret_cast<const u32x4 *>(grad_mask + (size_t)mj_ * C + piece_ * EPL);   \
+        }                                                                                       \
+    }
+#define BOXATTN_STAGE_ROWS()                                                                    \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
+        const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
+        *reinterpret_cast<u32x4 *>(&gstage[j_ * RS + piece_ * 16]) = grow[ps];                  \
+        if constexpr (INST)                                                                     \
+            *reinterpret_cast<u32x4 *>(&mstage[j_ * RS + piece_ * 16]) = mrow[ps];              \
+    }
+        float2 xy_c, xy_n = make_float2(0.f, 0.f);
+        float as_c, al_c, as_n = 0.f, al_n = 0.f;
+        fetch_point(fetch_ids(item.y), xy_c, as_c, al_c);
+        BOXATTN_FETCH_ROWS()
+        int rec_n = fetch_ids(item.y + R);
+        BOXATTN_STAGE_ROWS()                           // round 0 staged directly
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
-            if (tid < 64) pcnt[tid] = 0;
-            __syncthreads();
-            // ---- phase 1: one thread per record: geometry, ranks inside the pixel lists
-            int rank[4], pixk[4];
-            float wk[4];
-            bool use[4] = {false, false, false, false};
-            if (tid < n) {
-                const int lpid = rec[rr + tid];
-                const int q = lpid / LP, lp = lpid % LP;
-                const size_t row = ((size_t)b * Lq + q) * H + h;
-                const size_t pid = row * LP + lp;
-                const float2 xy = loc2[pid];
-                const Sample<float> sm = locate<float>(xy.x, xy.y, lv.H, lv.W);
-                wk[0] = sm.hh * sm.hw; wk[1] = sm.hh * sm.lw;
-                wk[2] = sm.lh * sm.hw; wk[3] = sm.lh * sm.lw;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
-                    if (sm.ok[k] && yy / BH == by && xx / BW == bx) {
-                        use[k] = true;
-                        pixk[k] = (yy - oy) * BW + (xx - ox);
-                        rank[k] = atomicAdd(&pcnt[pixk[k]], 1);
-                    }
-                }
-                rec_row[tid] = (int)row;
-                rec_as[tid] = w_sp[pid];
-                if constexpr (INST) {
-                    const int p = lp % P;
-                    rec_mrow[tid] = (int)((((size_t)b * Lq + q) * P + p) * H + h);
-                    rec_al[tid] = w_lv[pid];
-                }
+            const bool more = rr + R < item.z;         // wave-uniform
+            if (more && !(dbg & 4)) {                  // issue everything round r+1 needs
+                fetch_point(rec_n, xy_n, as_n, al_n);
+                BOXATTN_FETCH_ROWS()
+                rec_n = fetch_ids(rr + 2 * R);
             }
-            __syncthreads();
-            if (tid < 64) {                                   // exclusive scan of the PB counts
-                const int c = tid < PB ? pcnt[tid] : 0;
+            if (dbg & 8) continue;
+            if (lane <= PB) pcnt[lane] = 0;
+            wave_lds_sync();
+            // ---- phase 1: lane = record: geometry, rank inside the destination pixel lists.
+            //      Branch-free: corners outside this block go to dump slots.
+            const Sample<float> sm = locate<float>(xy_c.x, xy_c.y, lv.H, lv.W);
+            float wk[4] = {sm.hh * sm.hw, sm.hh * sm.lw, sm.lh * sm.hw, sm.lh * sm.lw};
+            int pixk[4], rank[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
+                const bool use = lane < n && sm.ok[k] && (yy >> 2) == by && (xx >> 3) == bx;
+                pixk[k] = use ? (yy - oy) * BW + (xx - ox) : PB;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rank[k] = (dbg & 2) ? 0 : atomicAdd(&pcnt[pixk[k]], 1);
+            wave_lds_sync();
+            {   // exclusive scan of the 32 pixel counts
+                const int c = lane < PB ? pcnt[lane] : 0;
                 int ic = c;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
+                for (int o = 1; o < PB; o <<= 1) {
                     const int t = __shfl_up(ic, o, 64);
-                    if (tid >= o) ic += t;
+                    if (lane >= o) ic += t;
                 }
-                poff[tid + 1] = ic;
-                if (tid == 0) poff[0] = 0;
+                if (lane < PB) poff[lane + 1] = ic;
+                if (lane == 0) poff[0] = 0;
             }
-            __syncthreads();
-            if (tid < n) {
+            wave_lds_sync();
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (use[k])
-                        ent[poff[pixk[k]] + rank[k]] = make_float2(wk[k], __int_as_float(tid));
+            for (int k = 0; k < 4; ++k) {
+                const int e = pixk[k] < PB ? poff[pixk[k]] + rank[k] : 4 * R + UNR;
+                if constexpr (INST)
+                    ent[e] = make_float4(wk[k] * as_c, wk[k] * al_c, __int_as_float(lane), 0.f);
+                else
+                    ent[e] = make_float2(wk[k] * as_c, __int_as_float(lane));
             }
-            // ---- stage t = a_s * g (+ a_l * g_mask) rows of this round's records
-            for (int j = mypix; j < n; j += PB) {
-                float g[VEC], t[VEC];
-                VecIO<ST, VEC>::ld(grad_out + (size_t)rec_row[j] * C + m * VEC, g);
-                const float as = rec_as[j];
+            wave_lds_sync();
+            // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
+            //      pixel's list, UNR entries per step (independent LDS reads in flight); the
+            //      padding of the last step reads the zero row with weight 0.
+            const int e0 = poff[mypix], e1 = (dbg & 1) ? e0 : poff[mypix + 1];
+            for (int e = e0; e < e1; e += UNR) {
+                Entry en[UNR];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) t[c] = g[c] * as;
+                for (int u = 0; u < UNR; ++u) en[u] = ent[e + u];
+                float wa[UNR], wb[UNR];
+                int jj[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const bool live = e + u < e1;
+                    wa[u] = live ? en[u].x : 0.f;
+                    if constexpr (INST) {
+                        wb[u] = live ? en[u].y : 0.f;
+                        jj[u] = live ? __float_as_int(en[u].z) : R;
+                    } else {
+                        wb[u] = 0.f;
+                        jj[u] = live ? __float_as_int(en[u].y) : R;
+                    }
+                }
+                float v[UNR][CH];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const ST *gp = reinterpret_cast<const ST *>(
+                        &gstage[jj[u] * RS + half * (ROWB / 2)]);
+#pragma unroll
+                    for (int c0 = 0; c0 < CH; c0 += EPL) {
+                        float t[EPL];
+                        VecIO<ST, EPL>::ld(gp + c0, t);
+#pragma unroll
+                        for (int c = 0; c < EPL; ++c) v[u][c0 + c] = t[c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) acc[c] += wa[u] * v[u][c];
                 if constexpr (INST) {
-                    float gm[VEC];
-                    VecIO<ST, VEC>::ld(grad_mask + (size_t)rec_mrow[j] * C + m * VEC, gm);
-                    const float al = rec_al[j];
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) t[c] += gm[c] * al;
+                    for (int u = 0; u < UNR; ++u) {
+                        const ST *mp = reinterpret_cast<const ST *>(
+                            &mstage[jj[u] * RS + half * (ROWB / 2)]);
+#pragma unroll
+                        for (int c0 = 0; c0 < CH; c0 += EPL) {
+                            float t[EPL];
+                            VecIO<ST, EPL>::ld(mp + c0, t);
+#pragma unroll
+                            for (int c = 0; c < EPL; ++c) acc[c0 + c] += wb[u] * t[c];
+                        }
+                    }
                 }
-                *reinterpret_cast<float4 *>(&tstage[j * TS + m * VEC]) =
-                    make_float4(t[0], t[1], t[2], t[3]);
             }
-            __syncthreads();
-            // ---- phase 2: every G-lane group owns one destination pixel
-            const int e1 = poff[mypix + 1];
-            for (int e = poff[mypix]; e < e1; ++e) {
-                const float2 en = ent[e];
-                const int j = __float_as_int(en.y);
-                const float4 tv = *reinterpret_cast<const float4 *>(&tstage[j * TS + m * VEC]);
-                acc[0] += en.x * tv.x; acc[1] += en.x * tv.y;
-                acc[2] += en.x * tv.z; acc[3] += en.x * tv.w;
+            wave_lds_sync();
+            if (more) {                                // stage round r+1 (rows have arrived)
+                BOXATTN_STAGE_ROWS()
+                xy_c = xy_n; as_c = as_n; al_c = al_n;
             }
-            __syncthreads();
         }
-        // ---- one row store per destination pixel
-        const int yy = oy + mypix / BW, xx = ox + mypix % BW;
-        if (yy < lv.H && xx < lv.W) {
-            float *dst = grad_value +
-                         (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
-                         m * VEC;
-            if (item.w == 1) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
+#undef BOXATTN_FETCH_ROWS
+#undef BOXATTN_STAGE_ROWS
+        // ---- store: one row (half) per lane; chunked blocks add their partial sums with fp32
+        //      atomics issued as full rows (two 128-byte rows per wave instruction for C=32)
+        if (dbg & 16) {
+        } else if (item.w == 1) {
+            const int yy = oy + mypix / BW, xx = ox + mypix % BW;
+            if (yy < lv.H && xx < lv.W) {
+                float *dst = grad_value +
+                             (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
+                             half * CH;
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) atomic_add(dst + c, acc[c]);
+                for (int c = 0; c < CH; c += 4)
+                    *reinterpret_cast<float4 *>(dst + c) =
+                        make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
             }
+        } else if (!(dbg & 32)) {
+            static_assert(R * RS >= PB * C * 4, "row stage doubles as the transpose tile");
+            float *t = reinterpret_cast<float *>(gstage);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) t[mypix * C + half * CH + c] = acc[c];
+            wave_lds_sync();
+            constexpr int LPX = (C < 64) ? C : 64;             // lanes per pixel row
+            constexpr int PXI = 64 / LPX;                      // pixels per instruction
+            for (int p0 = 0; p0 < PB; p0 += PXI) {
+                const int px = p0 + lane / LPX;
+                const int yy = oy + px / BW, xx = ox + px % BW;
+                if (yy < lv.H && xx < lv.W) {
+                    float *dst = grad_value +
+                                 (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C;
+                    for (int c = lane % LPX; c < C; c += LPX) atomic_add(dst + c, t[px * C + c]);
+                }
+            }
+            wave_lds_sync();
         }
-        __syncthreads();                                       // cur_item is reused
     }
 }
 

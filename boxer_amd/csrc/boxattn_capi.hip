@@ -9,11 +9,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
 #include "boxattn_binned.h"
 #include "boxattn_fast.h"
+#include "boxattn_gather2.h"
 #include "boxattn_generic.h"
 
 using namespace boxattn;
@@ -136,12 +138,19 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             const int G = fast_group(d);
             const int pairs = kWave / G;
             const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
+            const size_t vbytes = d.n_value() * sizeof(ST);
+            const bool gen2 = g_variant != 2 && vbytes < kOobOffset;   // buffer-load kernels
             ScopedKernelTimer timer(g_prof.fwd, st);
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
-        hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, st, \
-                           value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P,   \
-                           out, mask, n_qh);                                                  \
+        if (gen2)                                                                             \
+            hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST>), dim3(blocks), dim3(256), 0, st,   \
+                               value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, \
+                               out, mask, n_qh, (unsigned)vbytes);                            \
+        else                                                                                  \
+            hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, \
+                               st, value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, \
+                               d.P, out, mask, n_qh);                                         \
         break;
             switch (G) {
                 BOXATTN_FWD_CASE(4)
@@ -257,9 +266,9 @@ struct WsLayout {
     size_t offsets, items, records, gv_acc, total;
 };
 
-template <int G> bool make_plan_g(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
+inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
 {
-    constexpr int BW = BlockShape<G>::W, BH = BlockShape<G>::H;
+    constexpr int BW = 8, BH = 4;
     p.L = d.L;
     long long blk0 = 0, next_start = 0;
     for (int l = 0; l < d.L; ++l) {
@@ -282,6 +291,10 @@ template <int G> bool make_plan_g(const Dims &d, const int64_t *sh, const int64_
     if (blk0 == 0 || blk0 > kMaxBlocks || rec_cap > INT32_MAX / 2 ||
         (long long)d.B * d.Lq * d.H > INT32_MAX || (long long)d.B * d.Lq * d.P * d.H > INT32_MAX)
         return false;
+    int lp_bits = 0;
+    while ((1ll << lp_bits) < (long long)d.L * d.P) ++lp_bits;
+    if (((long long)d.Lq << lp_bits) > INT32_MAX) return false;
+    p.lp_bits = lp_bits;
     p.nblk = (int)blk0;
     p.rec_cap = (int)rec_cap;
     p.chunk = kChunk;
@@ -292,12 +305,7 @@ template <int G> bool make_plan_g(const Dims &d, const int64_t *sh, const int64_
 inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
 {
     if (!sh || !ls || !d.valid() || fast_group(d) == 0) return false;
-    switch (fast_group(d)) {
-        case 4: return make_plan_g<4>(d, sh, ls, p);
-        case 8: return make_plan_g<8>(d, sh, ls, p);
-        case 16: return make_plan_g<16>(d, sh, ls, p);
-    }
-    return false;
+    return make_plan_blocks(d, sh, ls, p);
 }
 
 inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
@@ -324,7 +332,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, float *gv_acc,
                float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
 {
-    constexpr int BW = BlockShape<G>::W, BH = BlockShape<G>::H;
+    constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
     int *counts = (int *)(ws + w.counts), *cursors = (int *)(ws + w.cursors);
     int *qhead = (int *)(ws + w.qhead), *n_items = (int *)(ws + w.n_items);
@@ -346,14 +354,22 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         ScopedKernelTimer timer(g_prof.bwd, st);
         const size_t n_qh = d.n_qh();
         const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
-        hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256), 0,
-                           st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S,
-                           d.H, d.L, d.Lq, d.P, gv_acc, grad_loc, grad_sp, grad_lv, n_qh);
+        const size_t vbytes = d.n_value() * sizeof(ST);
+        if (vbytes < kOobOffset)
+            hipLaunchKernelGGL((pointgrad2_kernel<ST, G, INST>), dim3(blocks), dim3(256), 0, st,
+                               value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S, d.H,
+                               d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv, n_qh, (unsigned)vbytes);
+        else
+            hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
+                               0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
+                               d.S, d.H, d.L, d.Lq, d.P, gv_acc, grad_loc, grad_sp, grad_lv, n_qh);
     }
-    const int wg_per_slice = std::max(1, 2048 / ns);
-    hipLaunchKernelGGL((binned_accumulate_kernel<ST, G, INST>), dim3(wg_per_slice, ns), dim3(256),
-                       0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
-                       offsets, items, n_items, qhead, records, gv_acc);
+    // persistent single-wave workgroups: ~13 per CU fit in LDS
+    const int wg_per_slice = getenv("BOXATTN_WGS") ? atoi(getenv("BOXATTN_WGS")) : std::max(1, (256 * 13 + ns - 1) / ns);
+    hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns),
+                       dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
+                       offsets, items, n_items, qhead, records, gv_acc,
+                       getenv("BOXATTN_DBG") ? atoi(getenv("BOXATTN_DBG")) : 0);
     return finish();
 }
 

@@ -164,6 +164,16 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Ordering point for LDS traffic inside ONE wavefront (single-wave workgroups): a wave's DS
+// operations execute in issue order, so only the compiler has to be kept from reordering.
+// Unlike __syncthreads() this does not drain vmcnt, i.e. global loads issued earlier stay in
+// flight across it (__syncthreads() carries an s_waitcnt vmcnt(0) and would expose their
+// full latency at every phase boundary).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
