@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_PKG, LIB_NAME)
 SOURCES = ["boxattn_capi.hip"]
 HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h", "boxattn_binned.h",
            "boxattn_gather2.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-shared", "-Wall", "-Wno-pass-failed"]
 
 _lib = None

@@ -37,6 +37,8 @@ struct BinLevel {
     int blk0;             // first block id of this level inside a slice
 };
 
+constexpr int kMaxBinLevels = 8;   // levels the binned backward plans for (BoxeR uses 2-5)
+
 struct BinPlan {
     int L;
     int nblk;             // blocks per (image, head) slice
@@ -44,7 +46,7 @@ struct BinPlan {
     int item_cap;         // work-item capacity per slice
     int chunk;            // records per work item
     int lp_bits;          // record = (query << lp_bits) | (level*P + point)
-    BinLevel lv[kMaxLevels];
+    BinLevel lv[kMaxBinLevels];
 };
 
 // Blocks touched by the (valid part of the) 2x2 footprint of a sample; at most 2x2.
@@ -191,11 +193,11 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     constexpr int BW = 8, BH = 4, PB = 32, R = 64;
     constexpr int CH = C / 2;                          // channels per lane while summing
     constexpr int ROWB = C * (int)sizeof(ST);          // bytes of one upstream-gradient row
-    constexpr int RS = ROWB + 16;                      // padded LDS row stride (bank spread)
-    constexpr int LPR = ROWB / 16;                     // lanes that stage one row, 16 B each
+    constexpr int RS = C * 4 + 16;                     // LDS row stride: fp32 row + pad (banks)
+    constexpr int LPR = ROWB / 16;                     // lanes that fetch one row, 16 B each
     constexpr int RPP = 64 / LPR;                      // rows staged per pass
     constexpr int NPASS = R / RPP;                     // staging passes per round
-    constexpr int EPL = 16 / (int)sizeof(ST);          // elements per 16-byte piece
+    constexpr int EPL = 16 / (int)sizeof(ST);          // elements per fetched 16-byte piece
     constexpr int UNR = 2;                             // list entries handled per step
     typedef typename std::conditional<INST, float4, float2>::type Entry;   // {w*a_s[, w*a_l], j}
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector: stays in VGPRs
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         const int blk = item.x;
         BinLevel lv = plan.lv[0];                    // select, no dynamic indexing of kernel args
 #pragma unroll
-        for (int k = 1; k < kMaxLevels; ++k)
+        for (int k = 1; k < kMaxBinLevels; ++k)
             if (k < plan.L && blk >= plan.lv[k].blk0) lv = plan.lv[k];
         const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
         const int oy = by * BH, ox = bx * BW;
@@ -255,6 +257,19 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             mr_n = INST ? (int)((((size_t)b * Lq + q) * P + lp % P) * H + h) : 0;
         };
         u32x4 grow[NPASS], mrow[INST ? NPASS : 1];     // rows in flight (registers)
+        // rows are staged as fp32 whatever the storage type: the conversion is paid once per
+        // record here instead of once per list entry in the summation loop
+        auto stage_piece = [&](unsigned char *dst, u32x4 v) {
+            if constexpr (sizeof(ST) == 4) {
+                *reinterpret_cast<u32x4 *>(dst) = v;
+            } else {
+                u32x4 lo, hi;
+                lo.x = v.x << 16; lo.y = v.x & 0xffff0000u; lo.z = v.y << 16; lo.w = v.y & 0xffff0000u;
+                hi.x = v.z << 16; hi.y = v.z & 0xffff0000u; hi.z = v.w << 16; hi.w = v.w & 0xffff0000u;
+                *reinterpret_cast<u32x4 *>(dst) = lo;
+                *reinterpret_cast<u32x4 *>(dst + 16) = hi;
+            }
+        };
 #define BOXATTN_FETCH_ROWS()                                                                    \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
@@ -269,9 +284,8 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #define BOXATTN_STAGE_ROWS()                                                                    \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
-        *reinterpret_cast<u32x4 *>(&gstage[j_ * RS + piece_ * 16]) = grow[ps];                  \
-        if constexpr (INST)                                                                     \
-            *reinterpret_cast<u32x4 *>(&mstage[j_ * RS + piece_ * 16]) = mrow[ps];              \
+        stage_piece(&gstage[j_ * RS + piece_ * EPL * 4], grow[ps]);                             \
+        if constexpr (INST) stage_piece(&mstage[j_ * RS + piece_ * EPL * 4], mrow[ps]);         \
     }
         float2 xy_c, xy_n = make_float2(0.f, 0.f);
         float as_c, al_c, as_n = 0.f, al_n = 0.f;
@@ -350,14 +364,12 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 float v[UNR][CH];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const ST *gp = reinterpret_cast<const ST *>(
-                        &gstage[jj[u] * RS + half * (ROWB / 2)]);
+                    const float4 *gp = reinterpret_cast<const float4 *>(
+                        &gstage[jj[u] * RS + half * (CH * 4)]);
 #pragma unroll
-                    for (int c0 = 0; c0 < CH; c0 += EPL) {
-                        float t[EPL];
-                        VecIO<ST, EPL>::ld(gp + c0, t);
-#pragma unroll
-                        for (int c = 0; c < EPL; ++c) v[u][c0 + c] = t[c];
+                    for (int c0 = 0; c0 < CH; c0 += 4) {
+                        const float4 t = gp[c0 / 4];
+                        v[u][c0] = t.x; v[u][c0 + 1] = t.y; v[u][c0 + 2] = t.z; v[u][c0 + 3] = t.w;
                     }
                 }
 #pragma unroll
@@ -367,14 +379,13 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 if constexpr (INST) {
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        const ST *mp = reinterpret_cast<const ST *>(
-                            &mstage[jj[u] * RS + half * (ROWB / 2)]);
+                        const float4 *mp = reinterpret_cast<const float4 *>(
+                            &mstage[jj[u] * RS + half * (CH * 4)]);
 #pragma unroll
-                        for (int c0 = 0; c0 < CH; c0 += EPL) {
-                            float t[EPL];
-                            VecIO<ST, EPL>::ld(mp + c0, t);
-#pragma unroll
-                            for (int c = 0; c < EPL; ++c) acc[c0 + c] += wb[u] * t[c];
+                        for (int c0 = 0; c0 < CH; c0 += 4) {
+                            const float4 t = mp[c0 / 4];
+                            acc[c0] += wb[u] * t.x; acc[c0 + 1] += wb[u] * t.y;
+                            acc[c0 + 2] += wb[u] * t.z; acc[c0 + 3] += wb[u] * t.w;
                         }
                     }
                 }

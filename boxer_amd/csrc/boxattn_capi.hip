@@ -304,7 +304,7 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
 
 inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
 {
-    if (!sh || !ls || !d.valid() || fast_group(d) == 0) return false;
+    if (!sh || !ls || !d.valid() || fast_group(d) == 0 || d.L > kMaxBinLevels) return false;
     return make_plan_blocks(d, sh, ls, p);
 }
 

@@ -108,10 +108,16 @@ template <typename T> struct Sample {
 template <typename T>
 __device__ __forceinline__ Sample<T> locate(T x, T y, int Hl, int Wl) {
     Sample<T> s;
-    // two roundings (mul, then sub), as in the reference (`loc_h * spatial_h - 0.5`); this
-    // translation unit is compiled with -ffp-contract=off so it is not fused.
-    const T h_im = y * (T)Hl - (T)0.5;
-    const T w_im = x * (T)Wl - (T)0.5;
+    T h_im, w_im;
+    {
+        // two roundings (mul, then sub), as in the reference (`loc_h * spatial_h - 0.5`, where
+        // the double constant keeps nvcc from fusing): no FMA contraction for the pixel
+        // coordinate, so the bilinear cell is chosen exactly like the reference chooses it.
+        // Everywhere else contraction stays on (the hot loops want v_fma / v_pk_fma).
+#pragma clang fp contract(off)
+        h_im = y * (T)Hl - (T)0.5;
+        w_im = x * (T)Wl - (T)0.5;
+    }
     s.inside = (h_im > (T)-1) && (w_im > (T)-1) && (h_im < (T)Hl) && (w_im < (T)Wl) &&
                Hl > 0 && Wl > 0;     // an empty level has nothing to read (keeps pix >= 0)
     // NaN / out-of-window points: keep the index arithmetic finite
