@@ -131,8 +131,11 @@ def n_points(dims):
 
 
 def algorithmic_bytes(dims, kind, elem):
-    """Compulsory HBM bytes of one forward / one backward: every tensor once,
-    value read capped at what is touched, grad_value written as fp32, zero-fills not counted."""
+    """Compulsory HBM bytes: every tensor once, value read capped at what is
+    touched, grad_value written as fp32, zero-fills not counted.  Returns (forward, backward)
+    totals of the op and the share of each kernel of the binned backward (DESIGN.md section 5:
+    the backward is split into a point-gradient kernel and an accumulate kernel, so the
+    locations / weights / upstream gradients are read by both)."""
     B, S, H, C, L, Lq, P = (dims[k] for k in ("B", "S", "H", "C", "L", "Lq", "P"))
     NP = B * Lq * H * L * P
     inst = kind == "instance"
@@ -140,9 +143,11 @@ def algorithmic_bytes(dims, kind, elem):
     W = (16 if inst else 12) * NP
     O = elem * B * Lq * H * C
     M = elem * B * Lq * P * H * C if inst else 0
+    GV = 4 * B * S * H * C
     fwd = Vr + W + O + M
-    bwd = Vr + W + O + M + 4 * B * S * H * C + W
-    return fwd, bwd
+    bwd = Vr + W + O + M + GV + W
+    per_kernel = {"fwd": fwd, "bwd_points": Vr + W + O + M + W, "bwd_accumulate": O + M + W + GV}
+    return fwd, bwd, per_kernel
 
 
 # --------------------------------------------------------------------------------------
@@ -251,6 +256,39 @@ def cpu_baseline(workload, budget_s=20.0):
 
 
 # --------------------------------------------------------------------------------------
+# timing protocol (shared with tests/test_dist_gloo.py, which runs it on CPU with gloo)
+# --------------------------------------------------------------------------------------
+def run_timed(step, steps, warmup, sync, dist=None, device=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on
+    both sides; returns the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def throughput(elapsed, points_per_rank_step, world, steps):
+    """Whole-job Gpoints/s (every rank processes its own images: weak scaling) and ms/step."""
+    total = points_per_rank_step * world * steps
+    return total / elapsed / 1e9, elapsed / steps * 1e3
+
+
+# --------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,53 +322,47 @@ def main():
     inp = make_inputs(args.workload, dtype, device, family=args.inputs, seed=rank)
     step = make_step(inp)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = run_timed(step, args.steps, args.warmup, torch.cuda.synchronize, dist, device)
 
     np_rank = n_points(inp["dims"])
-    total_points = np_rank * world * args.steps
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_points / elapsed / 1e9
+    value, ms_per_step = throughput(elapsed, np_rank, world, args.steps)
 
     phases = time_phases(inp)
     prof = kernel_profile(step, min(args.steps, 20))
     elem = 2 if dtype == torch.bfloat16 else 4
-    b_fwd, b_bwd = algorithmic_bytes(inp["dims"], inp["kind"], elem)
+    b_fwd, b_bwd, b_kernel = algorithmic_bytes(inp["dims"], inp["kind"], elem)
 
     if rank == 0:
-        # dominant kernel = the backward sampling/scatter kernel
-        if prof and prof.get("bwd_ms"):
-            dom_ms, src = prof["bwd_ms"], "HIP events around the backward kernel"
+        # dominant kernel = the longest of the op's kernels (HIP events recorded by the library
+        # around each launch, on the launch stream)
+        kern = {k: v for k, v in (prof or {}).items() if v["ms"]}
+        if kern:
+            dom = max((k for k in kern if k in b_kernel), key=lambda k: kern[k]["ms"])
+            dom_ms, dom_bytes = kern[dom]["ms"], b_kernel[dom]
+            src = "HIP events around every launch of the kernel (boxattn_profile_*)"
         else:
-            dom_ms, src = phases["bwd"], "HIP events around the backward call"
-        achieved = b_bwd / (dom_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "bwd_fast_kernel", "achieved": round(achieved, 1),
+            dom, dom_ms, dom_bytes = "bwd (whole call)", phases["bwd"], b_bwd
+            src = "HIP events around the backward call"
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        step_gbs = (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as fh:
+                t = json.load(fh)
+            key = "%s/%s/%s" % (args.workload, args.dtype, args.inputs)
+            traffic = t.get(key, {}).get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "algorithmic_bytes_per_launch": b_bwd,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                     "avg_launch_ms": round(dom_ms, 4), "timing": src,
                     "fwd_bwd": {"algorithmic_bytes": b_fwd + b_bwd,
-                                "achieved_GBs": round((b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9, 1),
-                                "frac": round((b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9
-                                              / HBM_PEAK_GBS, 4)},
-                    "fwd_ms": round(phases["fwd"], 4), "bwd_ms": round(phases["bwd"], 4)}
-        if prof:
-            roofline["kernels"] = prof
+                                "achieved_GBs": round(step_gbs, 1),
+                                "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+                    "fwd_ms": round(phases["fwd"], 4), "bwd_ms": round(phases["bwd"], 4),
+                    "kernels": {k: {"avg_ms": round(v["ms"], 4), "launches": v["launches"],
+                                    "algorithmic_bytes": b_kernel.get(k)}
+                                for k, v in kern.items()}}
         line = {
             "metric": "box-attn fwd+bwd Gsample-points/s + achieved HBM GB/s, BoxeR-R50 COCO shapes",
             "value": round(value, 4), "unit": "Gsample-points/s", "n_gpus": world,

@@ -38,7 +38,7 @@ EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def hipcc_path():
@@ -121,11 +121,13 @@ def profile_begin():
     load().boxattn_profile_begin()
 
 
+PROFILE_SLOTS = ("fwd", "bwd_points", "bwd_accumulate", "bwd_binning")
+
+
 def profile_end():
-    """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches): average kernel duration in ms."""
-    fs, bs = ctypes.c_double(0), ctypes.c_double(0)
-    fn, bn = ctypes.c_int(0), ctypes.c_int(0)
-    load().boxattn_profile_end(ctypes.byref(fs), ctypes.byref(fn), ctypes.byref(bs),
-                               ctypes.byref(bn))
-    return {"fwd_ms": fs.value / fn.value if fn.value else None, "fwd_launches": fn.value,
-            "bwd_ms": bs.value / bn.value if bn.value else None, "bwd_launches": bn.value}
+    """-> {slot: {"ms": average kernel duration, "launches": n}} for the four timing slots."""
+    ms = (ctypes.c_double * 4)()
+    n = (ctypes.c_int * 4)()
+    load().boxattn_profile_end(ms, n)
+    return {name: {"ms": (ms[i] / n[i] if n[i] else None), "launches": int(n[i])}
+            for i, name in enumerate(PROFILE_SLOTS)}

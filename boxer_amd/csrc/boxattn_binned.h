@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     // row R of the stages is all zeros: the target of padded (unused) list entries
     __shared__ __attribute__((aligned(16))) unsigned char gstage[(R + 1) * RS];
     __shared__ __attribute__((aligned(16))) unsigned char mstage[INST ? (R + 1) * RS : 16];
-    __shared__ __attribute__((aligned(16))) Entry ent[4 * R + UNR + 1];    // [4R+UNR] = dump slot
+    __shared__ __attribute__((aligned(16))) Entry ent[4 * R + 2 * UNR + 1];  // [4R+UNR] = dump slot
     __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
 
     const int s = blockIdx.y, b = s / H, h = s % H;
@@ -318,14 +318,13 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) rank[k] = (dbg & 2) ? 0 : atomicAdd(&pcnt[pixk[k]], 1);
             wave_lds_sync();
-            {   // exclusive scan of the 32 pixel counts
-                const int c = lane < PB ? pcnt[lane] : 0;
-                int ic = c;
-#pragma unroll
-                for (int o = 1; o < PB; o <<= 1) {
-                    const int t = __shfl_up(ic, o, 64);
-                    if (lane >= o) ic += t;
-                }
+            {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips)
+                int ic = lane < PB ? pcnt[lane] : 0;
+                ic += __builtin_amdgcn_update_dpp(0, ic, 0x111, 0xF, 0xF, true);   // row_shr:1
+                ic += __builtin_amdgcn_update_dpp(0, ic, 0x112, 0xF, 0xF, true);   // row_shr:2
+                ic += __builtin_amdgcn_update_dpp(0, ic, 0x114, 0xF, 0xF, true);   // row_shr:4
+                ic += __builtin_amdgcn_update_dpp(0, ic, 0x118, 0xF, 0xF, true);   // row_shr:8
+                ic += __builtin_amdgcn_update_dpp(0, ic, 0x142, 0xA, 0xF, true);   // row_bcast:15
                 if (lane < PB) poff[lane + 1] = ic;
                 if (lane == 0) poff[0] = 0;
             }
@@ -343,10 +342,16 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             //      pixel's list, UNR entries per step (independent LDS reads in flight); the
             //      padding of the last step reads the zero row with weight 0.
             const int e0 = poff[mypix], e1 = (dbg & 1) ? e0 : poff[mypix + 1];
+            Entry en_n[UNR];                           // entries of the next step (prefetched)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) en_n[u] = ent[e0 + u];
             for (int e = e0; e < e1; e += UNR) {
                 Entry en[UNR];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) en[u] = ent[e + u];
+                for (int u = 0; u < UNR; ++u) {
+                    en[u] = en_n[u];
+                    en_n[u] = ent[e + UNR + u];        // may run past the list: masked below
+                }
                 float wa[UNR], wb[UNR];
                 int jj[UNR];
 #pragma unroll

@@ -67,9 +67,10 @@ inline int finish()
 
 // ---- optional kernel timing (boxattn_profile_begin/_end) -------------------------------
 struct EventPair { hipEvent_t a, b; };
+enum { kSlotFwd = 0, kSlotBwdPoints = 1, kSlotBwdAccum = 2, kSlotBwdBin = 3, kNumSlots = 4 };
 struct Profile {
     bool on = false;
-    std::vector<EventPair> fwd, bwd;
+    std::vector<EventPair> ev[kNumSlots];
 } g_prof;
 constexpr size_t kMaxProfiled = 4096;
 
@@ -140,7 +141,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
             const size_t vbytes = d.n_value() * sizeof(ST);
             const bool gen2 = g_variant != 2 && vbytes < kOobOffset;   // buffer-load kernels
-            ScopedKernelTimer timer(g_prof.fwd, st);
+            ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
         if (gen2)                                                                             \
@@ -164,7 +165,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     }
     const size_t n = n_qh * d.C;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)1 << 20);
-    ScopedKernelTimer timer(g_prof.fwd, st);
+    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
     hipLaunchKernelGGL((fwd_generic_kernel<ST, INST>), dim3(blocks), dim3(256), 0, st, value,
                        shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.C, d.L, d.Lq, d.P, out, mask,
                        n);
@@ -206,7 +207,7 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
         if (!value) return (int)hipErrorInvalidValue;
     }
     if (n_qh && nv) {
-        ScopedKernelTimer timer(g_prof.bwd, st);
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
         bool done = false;
         if constexpr (!std::is_same<ST, double>::value) {
             if (fast_ok<ST>(d, value, loc, grad_out,
@@ -344,14 +345,17 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     const int q_per_wg = std::max(8, (int)(((long long)d.Lq * ns + 2047) / 2048));
     const dim3 bgrid((d.Lq + q_per_wg - 1) / q_per_wg, ns);
     const size_t bsh = (size_t)plan.nblk * 2 * sizeof(int);
-    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                       d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, counts, offsets, items,
-                       n_items, plan);
-    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                       d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+    {
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
+        hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
+                           d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, counts, offsets, items,
+                           n_items, plan);
+        hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
+                           d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+    }
     {   // grad_loc / grad_weight, query-major, no scatter
-        ScopedKernelTimer timer(g_prof.bwd, st);
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
         const size_t n_qh = d.n_qh();
         const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
         const size_t vbytes = d.n_value() * sizeof(ST);
@@ -366,6 +370,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     }
     // persistent single-wave workgroups: ~13 per CU fit in LDS
     const int wg_per_slice = getenv("BOXATTN_WGS") ? atoi(getenv("BOXATTN_WGS")) : std::max(1, (256 * 13 + ns - 1) / ns);
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
     hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns),
                        dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
                        offsets, items, n_items, qhead, records, gv_acc,
@@ -515,18 +520,16 @@ const char *boxattn_build_info(void)
 
 int boxattn_profile_begin(void)
 {
-    drain(g_prof.fwd, nullptr, nullptr);
-    drain(g_prof.bwd, nullptr, nullptr);
+    for (auto &v : g_prof.ev) drain(v, nullptr, nullptr);
     g_prof.on = true;
     return 0;
 }
 
-int boxattn_profile_end(double *fwd_ms_sum, int *fwd_launches, double *bwd_ms_sum,
-                        int *bwd_launches)
+int boxattn_profile_end(double *ms_sum, int *launches)
 {
     g_prof.on = false;
-    drain(g_prof.fwd, fwd_ms_sum, fwd_launches);
-    drain(g_prof.bwd, bwd_ms_sum, bwd_launches);
+    for (int i = 0; i < kNumSlots; ++i)
+        drain(g_prof.ev[i], ms_sum ? ms_sum + i : nullptr, launches ? launches + i : nullptr);
     return 0;
 }
 

@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 2
+#define BOXATTN_ABI_VERSION 3
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -162,14 +162,20 @@ int boxattn_set_variant(int variant);
 
 /*
  * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the
- * library brackets every launch of its main sampling kernels (forward kernel; backward
- * kernel -- without the grad_value zero-fill and the bf16 conversion pass) with hipEvents
- * recorded on the launch stream.  _end synchronises those events and returns the number of
- * launches seen and their summed durations in milliseconds.  At most 4096 launches are kept.
+ * library brackets the launches of its main kernels with hipEvents recorded on the launch
+ * stream, in four slots:
+ *   0  forward sampling kernel
+ *   1  backward, point gradients (grad_loc / grad_weight) -- or the whole atomic backward
+ *      kernel when the binned algorithm is not used
+ *   2  backward, grad_value accumulate kernel of the binned algorithm
+ *   3  backward, binning passes (count + scan + fill)
+ * Zero-fills and the bf16 conversion pass are not included.  _end synchronises the events and
+ * writes, per slot, the summed duration in milliseconds and the number of launches into the two
+ * 4-element arrays.  At most 4096 launches per slot are kept.
  */
+#define BOXATTN_PROFILE_SLOTS 4
 int boxattn_profile_begin(void);
-int boxattn_profile_end(double *fwd_ms_sum, int *fwd_launches, double *bwd_ms_sum,
-                        int *bwd_launches);
+int boxattn_profile_end(double *ms_sum, int *launches);
 
 #ifdef __cplusplus
 }
