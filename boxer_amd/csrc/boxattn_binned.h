@@ -46,6 +46,7 @@ struct BinPlan {
     int item_cap;         // work-item capacity per slice
     int chunk;            // records per work item
     int lp_bits;          // record = (query << lp_bits) | (level*P + point)
+    int n_slices;         // B * H
     BinLevel lv[kMaxBinLevels];
 };
 
@@ -207,7 +208,17 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     __shared__ __attribute__((aligned(16))) Entry ent[4 * R + 2 * UNR + 1];  // [4R+UNR] = dump slot
     __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
 
-    const int s = blockIdx.y, b = s / H, h = s % H;
+    // Workgroup -> (slice, worker) so that all workers of a slice sit on ONE XCD (workgroup b
+    // runs on XCD b % 8): a slice only reads the upstream-gradient / location / weight rows of
+    // its own head, so each XCD's L2 then holds 1/8 of those tensors instead of all of them.
+    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = bid % 8, k = bid / 8;
+    const int per_xcd = (n_slices + 7) / 8;                 // slices handled by one XCD
+    const int s = xcd + 8 * (k % per_xcd);
+    const int worker = k / per_xcd;                         // 0 .. workers-1 (grid is 8-aligned)
+    if (s >= n_slices || worker >= workers) return;
+    const int b = s / H, h = s % H;
     const int LP = plan.L * P;
     const int lane = threadIdx.x;
     const int mypix = lane >> 1, half = lane & 1;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     // Static round-robin over the slice's items (heaviest first): no work-queue atomics -- a
     // shared queue head is one cache line that every wave of the chip hammers (measured:
     // ~13 k dequeues on one line cost 160 us, more than the useful work).
-    for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
+    for (int it = worker; it < n_it; it += workers) {
         // coarse levels sit at the end of the list and carry the long chunked items: take
         // them first so the tail of the kernel is made of short items
         const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];

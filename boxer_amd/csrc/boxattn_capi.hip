@@ -296,6 +296,7 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     while ((1ll << lp_bits) < (long long)d.L * d.P) ++lp_bits;
     if (((long long)d.Lq << lp_bits) > INT32_MAX) return false;
     p.lp_bits = lp_bits;
+    p.n_slices = d.B * d.H;
     p.nblk = (int)blk0;
     p.rec_cap = (int)rec_cap;
     p.chunk = kChunk;
@@ -368,10 +369,13 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                                0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
                                d.S, d.H, d.L, d.Lq, d.P, gv_acc, grad_loc, grad_sp, grad_lv, n_qh);
     }
-    // persistent single-wave workgroups: ~13 per CU fit in LDS
-    const int wg_per_slice = getenv("BOXATTN_WGS") ? atoi(getenv("BOXATTN_WGS")) : std::max(1, (256 * 13 + ns - 1) / ns);
+    // persistent single-wave workgroups: ~13 per CU fit in LDS.  The kernel maps workgroups to
+    // (slice, worker) itself (XCD affinity); it needs workers * ceil(ns/8)*8 workgroups.
+    const int ns8 = (ns + 7) / 8 * 8;
+    const int wg_per_slice = getenv("BOXATTN_WGS") ? atoi(getenv("BOXATTN_WGS"))
+                                                   : std::max(1, (256 * 13 + ns8 - 1) / ns8);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
-    hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns),
+    hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns8),
                        dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
                        offsets, items, n_items, qhead, records, gv_acc,
                        getenv("BOXATTN_DBG") ? atoi(getenv("BOXATTN_DBG")) : 0);
