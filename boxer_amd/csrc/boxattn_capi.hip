@@ -145,9 +145,10 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
         if (gen2)                                                                             \
-            hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST>), dim3(blocks), dim3(256), 0, st,   \
-                               value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, \
-                               out, mask, n_qh, (unsigned)vbytes);                            \
+            hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, (sizeof(ST) == 2 && GG >= 4) ? 4 : GG>), \
+                               dim3(blocks), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
+                               w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh,               \
+                               (unsigned)vbytes);                                             \
         else                                                                                  \
             hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, \
                                st, value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, \

@@ -65,7 +65,7 @@ __device__ __forceinline__ void corner_offsets(const Sample<float> &s, unsigned 
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <typename ST, int G, bool INST>
+template <typename ST, int G, bool INST, int U = G>
 __global__ __launch_bounds__(256) void fwd2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     constexpr int VEC = 4, C = VEC * G, PAIRS = kWave / G;
     typedef typename std::conditional<INST, GeoInst, GeoBox>::type Geo;
     __shared__ LevelTable lv;
-    __shared__ __attribute__((aligned(16))) Geo geo_all[4][kWave];
+    // one pad slot per G-lane group: the groups' broadcast reads then fall on different banks
+    __shared__ __attribute__((aligned(16))) Geo geo_all[4][kWave + kWave / G];
     load_levels(lv, shapes, lsi, L);
 
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const bool active = qh < n_qh;
     if (!active) qh = n_qh - 1;
     const int slot = lane % G;                      // step A: point slot; step B: channel chunk
-    const int grp0 = lane & ~(G - 1);
+    const int grp0 = (lane & ~(G - 1)) + lane / G;  // padded tile index of the group's slot 0
+    const int myslot = grp0 + lane % G;
     const int h = (int)(qh % H);
     const size_t bq = qh / H;
     const unsigned b = (unsigned)(bq / Lq);
@@ -118,20 +120,23 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                     for (int k = 0; k < 4; ++k) { g.off[k] = kOobOffset; g.w[k] = 0.f; }
                 }
                 wave_lds_sync();                   // previous tile fully consumed
-                geo[lane] = g;
+                geo[myslot] = g;
                 wave_lds_sync();
             }
-            // ---- step B
+            // ---- step B (U points' loads in flight at a time)
+#pragma unroll 1
+            for (int tb = 0; tb < G; tb += U) {
 #pragma unroll
-            for (int t = 0; t < G; ++t) {
-                const Geo g = geo[grp0 + t];
-                float v[4][VEC];
+                for (int t = tb; t < tb + U; ++t) {
+                    const Geo g = geo[grp0 + t];
+                    float v[4][VEC];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) BufLd<ST>::ld(rs, g.off[k] + lane_off, v[k]);
+                    for (int k = 0; k < 4; ++k) BufLd<ST>::ld(rs, g.off[k] + lane_off, v[k]);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c)
-                    acc[c] += g.w[0] * v[0][c] + g.w[1] * v[1][c] + g.w[2] * v[2][c] +
-                              g.w[3] * v[3][c];
+                    for (int c = 0; c < VEC; ++c)
+                        acc[c] += g.w[0] * v[0][c] + g.w[1] * v[1][c] + g.w[2] * v[2][c] +
+                                  g.w[3] * v[3][c];
+                }
             }
         }
     } else {
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                     }
                     g.pad0 = 0.f; g.pad1 = 0.f;
                     wave_lds_sync();
-                    geo[lane] = g;
+                    geo[myslot] = g;
                     wave_lds_sync();
                 }
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
 {
     constexpr int VEC = 4, C = VEC * G, PAIRS = kWave / G;
     __shared__ LevelTable lv;
-    __shared__ __attribute__((aligned(16))) GeoBox geo_all[4][kWave];
+    __shared__ __attribute__((aligned(16))) GeoBox geo_all[4][kWave + kWave / G];
     load_levels(lv, shapes, lsi, L);
 
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
@@ -214,7 +219,8 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const bool active = qh < n_qh;
     if (!active) qh = n_qh - 1;
     const int slot = lane % G;
-    const int grp0 = lane & ~(G - 1);
+    const int grp0 = (lane & ~(G - 1)) + lane / G;  // padded tile index of the group's slot 0
+    const int myslot = grp0 + lane % G;
     const int h = (int)(qh % H);
     const size_t bq = qh / H;
     const unsigned b = (unsigned)(bq / Lq);
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
             for (int k = 0; k < 4; ++k) gg.off[k] = kOobOffset;
         }
         wave_lds_sync();
-        geo[lane] = gg;
+        geo[myslot] = gg;
         wave_lds_sync();
 
         // ---- step B: corner sums of the G points of this lane's pair
