@@ -9,10 +9,11 @@
 //
 //   1. bin_kernel<count>   one pass over the sampling locations: every sample point is
 //                          assigned to the 32-pixel blocks (8x4, per image, head, level)
-//                          its 2x2 footprint touches; per-workgroup LDS histograms, one
-//                          global integer atomic per (workgroup, block).
-//   2. bin_scan_kernel     per (image, head) slice: exclusive scan -> record offsets and
-//                          the work-item list (blocks with many points are cut into chunks).
+//                          its 2x2 footprint touches; per-workgroup LDS histograms, written
+//                          out densely per workgroup (no global atomics).
+//   2. bin_scan_kernel     per (image, head) slice: prefix over the workgroups and exclusive
+//                          scan over the blocks -> every workgroup's first slot in every bin,
+//                          and the work-item list (big bins are cut into chunks).
 //   3. bin_kernel<fill>    same pass again, now writing the point ids into their bins.
 //   4. bwd_fast_kernel<SCATTER=false> (boxattn_fast.h): grad_loc / grad_weight, query-major.
 //   5. binned_accumulate_kernel  one wavefront per work item: records -> geometry ->
@@ -37,6 +38,7 @@ struct BinLevel {
     int blk0;             // first block id of this level inside a slice
 };
 
+constexpr int kScanSub = 8, kScanWgPerSub = 16;   // bin_scan_a_kernel: sub-ranges of workgroups
 constexpr int kMaxBinLevels = 8;   // levels the binned backward plans for (BoxeR uses 2-5)
 
 struct BinPlan {
@@ -50,23 +52,23 @@ struct BinPlan {
     BinLevel lv[kMaxBinLevels];
 };
 
-// Blocks touched by the (valid part of the) 2x2 footprint of a sample; at most 2x2.
+// Blocks touched by the (valid part of the) 2x2 footprint of a sample: up to 2 block rows x 2
+// block columns.  Branch-free: always four candidates, `dump` for the unused ones.
 template <int BW, int BH>
-__device__ __forceinline__ int touched_blocks(const Sample<float> &s, const BinLevel &lv,
-                                              int (&blk)[4])
+__device__ __forceinline__ void touched_blocks(const Sample<float> &s, const BinLevel &lv, int dump,
+                                               int (&blk)[4])
 {
-    if (!s.inside) return 0;
     const bool ya = s.ok[0] || s.ok[1], yb = s.ok[2] || s.ok[3];
     const bool xa = s.ok[0] || s.ok[2], xb = s.ok[1] || s.ok[3];
-    int rows[2], cols[2], nr = 0, nc = 0;
-    if (ya) rows[nr++] = s.y0 / BH;
-    if (yb) { const int r = (s.y0 + 1) / BH; if (nr == 0 || r != rows[0]) rows[nr++] = r; }
-    if (xa) cols[nc++] = s.x0 / BW;
-    if (xb) { const int c = (s.x0 + 1) / BW; if (nc == 0 || c != cols[0]) cols[nc++] = c; }
-    int n = 0;
-    for (int i = 0; i < nr; ++i)
-        for (int j = 0; j < nc; ++j) blk[n++] = lv.blk0 + rows[i] * lv.nbx + cols[j];
-    return n;
+    const int ra = s.y0 / BH, rb = (s.y0 + 1) / BH;          // only used when the row is valid
+    const int ca = s.x0 / BW, cb = (s.x0 + 1) / BW;
+    const bool use_rb = yb && (!ya || rb != ra);             // second row adds a new block row
+    const bool use_cb = xb && (!xa || cb != ca);
+    const int base_a = lv.blk0 + ra * lv.nbx, base_b = lv.blk0 + rb * lv.nbx;
+    blk[0] = (ya && xa) ? base_a + ca : dump;
+    blk[1] = (ya && use_cb) ? base_a + cb : dump;
+    blk[2] = (use_rb && xa) ? base_b + ca : dump;
+    blk[3] = (use_rb && use_cb) ? base_b + cb : dump;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -75,65 +77,102 @@ __device__ __forceinline__ int touched_blocks(const Sample<float> &s, const BinL
 template <int BW, int BH, bool FILL>
 __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc, BinPlan plan,
                                                   int H, int Lq, int P, int q_per_wg,
-                                                  int *__restrict__ counts,
-                                                  int *__restrict__ cursors,
+                                                  int *__restrict__ part,
+                                                  const int *__restrict__ subtot,
                                                   const int *__restrict__ offsets,
                                                   int *__restrict__ records)
 {
+    // part[slice][workgroup][block]: after the count pass the number of records this workgroup
+    // has for the block; the scan kernel turns it into the workgroup's first slot inside the
+    // block's bin.  No global atomics anywhere in the binning (they cost ~20 us per pass:
+    // ~200 k single-lane atomics on 226 cache lines), and the record order is deterministic.
     extern __shared__ int sh_bins[];
     int *hist = sh_bins;
-    int *base = sh_bins + plan.nblk;
     const int s = blockIdx.y, b = s / H, h = s % H;
     const int LP = plan.L * P;
     const int q0 = blockIdx.x * q_per_wg;
     const int q1 = min(q0 + q_per_wg, Lq);
     const int n_pts = (q1 - q0) * LP;
-    for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x) hist[k] = 0;
+    int *mypart = part + ((size_t)s * gridDim.x + blockIdx.x) * plan.nblk;
+    __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane below (no select chains)
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
+    }
+    const int wps = ((int)gridDim.x + kScanSub - 1) / kScanSub;       // as in bin_scan_a_kernel
+    const int *mysub = subtot + ((size_t)s * kScanSub + blockIdx.x / wps) * plan.nblk;
+    for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x)
+        hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
     __syncthreads();
 
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    for (int i = threadIdx.x; i < n_pts; i += blockDim.x) {
-        const int q = q0 + i / LP, lp = i % LP, l = lp / P;
-        const size_t pid = (((size_t)b * Lq + q) * H + h) * LP + lp;
-        const float2 xy = loc2[pid];
-        const Sample<float> sm = locate<float>(xy.x, xy.y, plan.lv[l].H, plan.lv[l].W);
-        int blk[4];
-        const int n = touched_blocks<BW, BH>(sm, plan.lv[l], blk);
-        for (int j = 0; j < n; ++j) atomicAdd(&hist[blk[j]], 1);
-    }
-    __syncthreads();
-    const size_t sb = (size_t)s * plan.nblk;
-    if (!FILL) {
-        for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x)
-            if (hist[k]) atomicAdd(&counts[sb + k], hist[k]);
-        return;
-    }
-    for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x) {
-        const int c = hist[k];
-        base[k] = c ? atomicAdd(&cursors[sb + k], c) + offsets[(size_t)s * (plan.nblk + 1) + k]
-                    : 0;
-        hist[k] = 0;
-    }
-    __syncthreads();
+    constexpr int U = 4;                          // points per thread per step (loads in flight)
+    const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
+    const size_t qstride = (size_t)H * LP;                          // points between queries
+    const float rcp_lp = 1.0f / (float)LP;
     int *rec = records + (size_t)s * plan.rec_cap;
-    for (int i = threadIdx.x; i < n_pts; i += blockDim.x) {
-        const int q = q0 + i / LP, lp = i % LP, l = lp / P;
-        const size_t pid = (((size_t)b * Lq + q) * H + h) * LP + lp;
-        const float2 xy = loc2[pid];
-        const Sample<float> sm = locate<float>(xy.x, xy.y, plan.lv[l].H, plan.lv[l].W);
-        int blk[4];
-        const int n = touched_blocks<BW, BH>(sm, plan.lv[l], blk);
-        for (int j = 0; j < n; ++j) {
-            const int slot = base[blk[j]] + atomicAdd(&hist[blk[j]], 1);
-            rec[slot] = (q << plan.lp_bits) | lp;        // point id inside the slice
+    for (int i0 = threadIdx.x; i0 < n_pts; i0 += blockDim.x * U) {
+        float2 xy[U];
+        int lp[U], ql[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * (int)blockDim.x, n_pts - 1);
+            divmod_small(i, LP, rcp_lp, ql[u], lp[u]);
+            xy[u] = loc2[pid0 + ql[u] * qstride + lp[u]];
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * (int)blockDim.x >= n_pts) break;
+            const BinLevel lv = s_lv[level_of(lp[u], P, plan.L)];
+            const Sample<float> sm = locate<float>(xy[u].x, xy[u].y, lv.H, lv.W);
+            int blk[4];
+            touched_blocks<BW, BH>(sm, lv, -1, blk);
+            // predicated, not redirected to a dump slot: same-address LDS atomics serialise per
+            // lane, a shared dump slot made this kernel 1.6x slower
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (blk[j] >= 0) {
+                    const int slot = atomicAdd(&hist[blk[j]], 1);      // LDS
+                    if (FILL) rec[slot] = ((q0 + ql[u]) << plan.lp_bits) | lp[u];
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x) mypart[k] = hist[k];
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // 2: per-slice scan.  grid = slices, block 256.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bin_scan_kernel(const int *__restrict__ counts,
+// Two small kernels so that no thread walks more than 16 dependent-free loads:
+//   A  grid (kScanSub, slices): prefix of the per-workgroup counts inside each of the
+//      kScanSub sub-ranges of workgroups (<= kScanWgPerSub workgroups each), sub-range totals;
+//   B  grid (slices): prefix over the sub-ranges, then the exclusive scan over the blocks.
+__global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part, int n_wg,
+                                                         int *__restrict__ subtot, BinPlan plan)
+{
+    const int sub = blockIdx.x, s = blockIdx.y;
+    const int wps = (n_wg + kScanSub - 1) / kScanSub;
+    const int w_lo = sub * wps, w_hi = min(n_wg, w_lo + wps);
+    int *sp = part + (size_t)s * n_wg * plan.nblk;
+    for (int k = threadIdx.x; k < plan.nblk; k += 256) {
+        int t[kScanWgPerSub], sum = 0;
+#pragma unroll
+        for (int u = 0; u < kScanWgPerSub; ++u)
+            t[u] = w_lo + u < w_hi ? sp[(size_t)(w_lo + u) * plan.nblk + k] : 0;
+#pragma unroll
+        for (int u = 0; u < kScanWgPerSub; ++u) {
+            if (w_lo + u < w_hi) sp[(size_t)(w_lo + u) * plan.nblk + k] = sum;
+            sum += t[u];
+        }
+        subtot[((size_t)s * kScanSub + sub) * plan.nblk + k] = sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
                                                        int *__restrict__ offsets,
                                                        int4 *__restrict__ items,
                                                        int *__restrict__ n_items, BinPlan plan)
@@ -145,7 +184,18 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(const int *__restrict__ c
     __syncthreads();
     for (int k0 = 0; k0 < plan.nblk; k0 += 256) {
         const int k = k0 + threadIdx.x;
-        const int c = k < plan.nblk ? counts[(size_t)s * plan.nblk + k] : 0;
+        int c = 0;
+        if (k < plan.nblk) {                       // sub-range totals -> sub-range first slots
+            int t[kScanSub];
+#pragma unroll
+            for (int u = 0; u < kScanSub; ++u)
+                t[u] = subtot[((size_t)s * kScanSub + u) * plan.nblk + k];
+#pragma unroll
+            for (int u = 0; u < kScanSub; ++u) {
+                subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;
+                c += t[u];
+            }
+        }
         const int nch = (c + plan.chunk - 1) / plan.chunk;
         int ic = c, in = nch;                                 // inclusive wave scans
 #pragma unroll
@@ -188,8 +238,8 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const float *__restrict__ loc, const float *__restrict__ w_sp,
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
     const int *__restrict__ offsets, const int4 *__restrict__ items,
-    const int *__restrict__ n_items, int *__restrict__ qhead, const int *__restrict__ records,
-    float *__restrict__ grad_value, int dbg)
+    const int *__restrict__ n_items, const int *__restrict__ records,
+    float *__restrict__ grad_value)
 {
     constexpr int BW = 8, BH = 4, PB = 32, R = 64;
     constexpr int CH = C / 2;                          // channels per lane while summing
@@ -231,9 +281,10 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         if constexpr (INST) reinterpret_cast<int *>(&mstage[R * RS])[i] = 0;
     }
 
-    // Static round-robin over the slice's items (heaviest first): no work-queue atomics -- a
-    // shared queue head is one cache line that every wave of the chip hammers (measured:
-    // ~13 k dequeues on one line cost 160 us, more than the useful work).
+    // Static round-robin over the slice's items, heaviest first.  A dynamic queue was slower
+    // both ways it was tried: with the 16 queue heads in one cache line every dequeue of the
+    // chip serialised on that line (13 k atomics = 160 us), and with padded heads the dequeue
+    // latency still cost 10 % (184 vs 167 us).
     for (int it = worker; it < n_it; it += workers) {
         // coarse levels sit at the end of the list and carry the long chunked items: take
         // them first so the tail of the kernel is made of short items
@@ -307,12 +358,11 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;         // wave-uniform
-            if (more && !(dbg & 4)) {                  // issue everything round r+1 needs
+            if (more) {                                // issue everything round r+1 needs
                 fetch_point(rec_n, xy_n, as_n, al_n);
                 BOXATTN_FETCH_ROWS()
                 rec_n = fetch_ids(rr + 2 * R);
             }
-            if (dbg & 8) continue;
             if (lane <= PB) pcnt[lane] = 0;
             wave_lds_sync();
             // ---- phase 1: lane = record: geometry, rank inside the destination pixel lists.
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 pixk[k] = use ? (yy - oy) * BW + (xx - ox) : PB;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rank[k] = (dbg & 2) ? 0 : atomicAdd(&pcnt[pixk[k]], 1);
+            for (int k = 0; k < 4; ++k) rank[k] = atomicAdd(&pcnt[pixk[k]], 1);
             wave_lds_sync();
             {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips)
                 int ic = lane < PB ? pcnt[lane] : 0;
@@ -352,7 +402,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
             //      pixel's list, UNR entries per step (independent LDS reads in flight); the
             //      padding of the last step reads the zero row with weight 0.
-            const int e0 = poff[mypix], e1 = (dbg & 1) ? e0 : poff[mypix + 1];
+            const int e0 = poff[mypix], e1 = poff[mypix + 1];
             Entry en_n[UNR];                           // entries of the next step (prefetched)
 #pragma unroll
             for (int u = 0; u < UNR; ++u) en_n[u] = ent[e0 + u];
@@ -416,8 +466,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #undef BOXATTN_STAGE_ROWS
         // ---- store: one row (half) per lane; chunked blocks add their partial sums with fp32
         //      atomics issued as full rows (two 128-byte rows per wave instruction for C=32)
-        if (dbg & 16) {
-        } else if (item.w == 1) {
+        if (item.w == 1) {
             const int yy = oy + mypix / BW, xx = ox + mypix % BW;
             if (yy < lv.H && xx < lv.W) {
                 float *dst = grad_value +
@@ -428,7 +477,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                     *reinterpret_cast<float4 *>(dst + c) =
                         make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
             }
-        } else if (!(dbg & 32)) {
+        } else {
             static_assert(R * RS >= PB * C * 4, "row stage doubles as the transpose tile");
             float *t = reinterpret_cast<float *>(gstage);
 #pragma unroll

@@ -9,7 +9,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -259,13 +258,14 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
 constexpr int kChunk = 1024;          // records per work item
-constexpr int kMaxBlocks = 8192;      // per (image, head) slice: 2 LDS ints each in bin_kernel
+constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
-    size_t counts, cursors, qhead, n_items, zero_bytes;     // [0, zero_bytes) is memset to 0
-    size_t offsets, items, records, gv_acc, total;
+    size_t n_items;
+    size_t part, subtot, offsets, items, records, gv_acc, total;
+    int q_per_wg, n_wg;                                     // launch geometry of the bin passes
 };
 
 inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
@@ -296,6 +296,7 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     int lp_bits = 0;
     while ((1ll << lp_bits) < (long long)d.L * d.P) ++lp_bits;
     if (((long long)d.Lq << lp_bits) > INT32_MAX) return false;
+    if ((long long)d.L * d.P > (1 << 16)) return false;       // keeps per-workgroup point counts < 2^24
     p.lp_bits = lp_bits;
     p.n_slices = d.B * d.H;
     p.nblk = (int)blk0;
@@ -315,12 +316,16 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
 {
     const size_t ns = (size_t)d.B * d.H;
     WsLayout w;
+    // ~2048 workgroups for the two binning passes
+    // ... and at most kScanSub * kScanWgPerSub workgroups per slice (bin_scan_a_kernel)
+    w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + 2047) / 2048));
+    w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
+                                          (kScanSub * kScanWgPerSub));
+    w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
     size_t o = 0;
-    w.counts = o;  o += align_up(ns * p.nblk * 4);
-    w.cursors = o; o += align_up(ns * p.nblk * 4);
-    w.qhead = o;   o += align_up(ns * 4);
     w.n_items = o; o += align_up(ns * 4);
-    w.zero_bytes = o;
+    w.part = o;    o += align_up(ns * w.n_wg * (size_t)p.nblk * 4);
+    w.subtot = o;  o += align_up(ns * kScanSub * (size_t)p.nblk * 4);
     w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
     w.items = o;   o += align_up(ns * p.item_cap * 16);
     w.records = o; o += align_up(ns * (size_t)p.rec_cap * 4);
@@ -337,24 +342,22 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
-    int *counts = (int *)(ws + w.counts), *cursors = (int *)(ws + w.cursors);
-    int *qhead = (int *)(ws + w.qhead), *n_items = (int *)(ws + w.n_items);
+    int *part = (int *)(ws + w.part), *subtot = (int *)(ws + w.subtot);
+    int *n_items = (int *)(ws + w.n_items);      // every scratch word is written before it is read
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items);
-    hipError_t e = hipMemsetAsync(ws, 0, w.zero_bytes, st);
-    if (e != hipSuccess) return (int)e;
-    // ~2048 workgroups for the two binning passes
-    const int q_per_wg = std::max(8, (int)(((long long)d.Lq * ns + 2047) / 2048));
-    const dim3 bgrid((d.Lq + q_per_wg - 1) / q_per_wg, ns);
-    const size_t bsh = (size_t)plan.nblk * 2 * sizeof(int);
+    const dim3 bgrid(w.n_wg, ns);
+    const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);   // + dump slot
     {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
         hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                           d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, counts, offsets, items,
+                           d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
+        hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
+                           subtot, plan);
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items,
                            n_items, plan);
         hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                           d.Lq, d.P, q_per_wg, counts, cursors, offsets, records);
+                           d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
     }
     {   // grad_loc / grad_weight, query-major, no scatter
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
@@ -373,13 +376,11 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // persistent single-wave workgroups: ~13 per CU fit in LDS.  The kernel maps workgroups to
     // (slice, worker) itself (XCD affinity); it needs workers * ceil(ns/8)*8 workgroups.
     const int ns8 = (ns + 7) / 8 * 8;
-    const int wg_per_slice = getenv("BOXATTN_WGS") ? atoi(getenv("BOXATTN_WGS"))
-                                                   : std::max(1, (256 * 13 + ns8 - 1) / ns8);
+    const int wg_per_slice = std::max(1, (256 * 13 + ns8 - 1) / ns8);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
     hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns8),
                        dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
-                       offsets, items, n_items, qhead, records, gv_acc,
-                       getenv("BOXATTN_DBG") ? atoi(getenv("BOXATTN_DBG")) : 0);
+                       offsets, items, n_items, records, gv_acc);
     return finish();
 }
 

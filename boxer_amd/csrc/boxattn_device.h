@@ -147,6 +147,24 @@ __device__ __forceinline__ Sample<T> locate(T x, T y, int Hl, int Wl) {
 }
 
 // ---------------------------------------------------------------------------------------
+// cheap integer helpers (runtime divisors would otherwise cost ~30 VALU per division)
+// ---------------------------------------------------------------------------------------
+// n / d and n % d for 0 <= n < 2^24 with rcp = 1.0f / d: float estimate + one correction.
+__device__ __forceinline__ void divmod_small(int n, int d, float rcp, int &q, int &r) {
+    q = (int)((float)n * rcp);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+// level of flattened point index lp = l * P + p: a compare chain instead of a division
+__device__ __forceinline__ int level_of(int lp, int P, int L) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) l += (k < L && lp >= k * P) ? 1 : 0;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------
 // cross-lane sums
 // ---------------------------------------------------------------------------------------
 // Sum over aligned groups of G consecutive lanes, result in every lane of the group.
