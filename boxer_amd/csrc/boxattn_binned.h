@@ -20,9 +20,12 @@
 //                          per-pixel entry lists in LDS (integer LDS atomics for the ranks);
 //                          the records' upstream-gradient rows are staged once in LDS; each
 //                          lane pair owns one destination pixel and sums (w*a) * row over its
-//                          list in registers; one plain coalesced row store per pixel (fp32
-//                          atomics only for the few blocks that were cut into chunks, i.e.
-//                          the coarse levels).
+//                          list in registers; one plain coalesced row store per pixel in the
+//                          storage type.  Blocks cut into chunks (the coarse levels) write
+//                          fp32 partial tiles instead.
+//   6. combine_partials_kernel   sums the partial tiles of the chunked blocks.
+// No zero-fill, no conversion pass, no float atomics (run-to-run differences are limited to
+// the fp32 summation order inside a bin, which follows integer LDS atomics).
 //
 // The result is the same sum as the reference's, in a different (still unspecified) order.
 #pragma once
@@ -49,6 +52,7 @@ struct BinPlan {
     int chunk;            // records per work item
     int lp_bits;          // record = (query << lp_bits) | (level*P + point)
     int n_slices;         // B * H
+    int pslot_cap;        // partial-tile slots per slice (chunks of blocks cut into several items)
     BinLevel lv[kMaxBinLevels];
 };
 
@@ -175,17 +179,20 @@ __global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part,
 __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
                                                        int *__restrict__ offsets,
                                                        int4 *__restrict__ items,
+                                                       int4 *__restrict__ combos,
                                                        int *__restrict__ n_items, BinPlan plan)
 {
-    __shared__ int wsum_c[4], wsum_n[4];
-    __shared__ int carry_c, carry_n;
+    // four running sums over the blocks: records, items, partial slots, chunked blocks
+    __shared__ int wsum[4][4];
+    __shared__ int carry[4];
     const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { carry_c = 0; carry_n = 0; }
+    if (threadIdx.x < 4) carry[threadIdx.x] = 0;
     __syncthreads();
     for (int k0 = 0; k0 < plan.nblk; k0 += 256) {
         const int k = k0 + threadIdx.x;
+        const bool live = k < plan.nblk;
         int c = 0;
-        if (k < plan.nblk) {                       // sub-range totals -> sub-range first slots
+        if (live) {                                // sub-range totals -> sub-range first slots
             int t[kScanSub];
 #pragma unroll
             for (int u = 0; u < kScanSub; ++u)
@@ -196,31 +203,49 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
                 c += t[u];
             }
         }
-        const int nch = (c + plan.chunk - 1) / plan.chunk;
-        int ic = c, in = nch;                                 // inclusive wave scans
+        // every block gets at least one item (an empty block still has to be zero-filled)
+        const int nch = live ? max(1, (c + plan.chunk - 1) / plan.chunk) : 0;
+        const int v[4] = {c, nch, nch > 1 ? nch : 0, nch > 1 ? 1 : 0};
+        int inc[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tc = __shfl_up(ic, o, 64), tn = __shfl_up(in, o, 64);
-            if (lane >= o) { ic += tc; in += tn; }
+        for (int i = 0; i < 4; ++i) {
+            int x = v[i];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(x, o, 64);
+                if (lane >= o) x += t;
+            }
+            inc[i] = x;
+            if (lane == 63) wsum[i][wv] = x;
         }
-        if (lane == 63) { wsum_c[wv] = ic; wsum_n[wv] = in; }
         __syncthreads();
-        int pc = carry_c, pn = carry_n;
-        for (int w = 0; w < wv; ++w) { pc += wsum_c[w]; pn += wsum_n[w]; }
-        const int ec = pc + ic - c, en = pn + in - nch;       // exclusive
-        if (k < plan.nblk) {
-            offsets[(size_t)s * (plan.nblk + 1) + k] = ec;
+        int ex[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int pre = carry[i];
+            for (int w = 0; w < wv; ++w) pre += wsum[i][w];
+            ex[i] = pre + inc[i] - v[i];
+        }
+        if (live) {
+            offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
             for (int j = 0; j < nch; ++j)
-                items[(size_t)s * plan.item_cap + en + j] =
-                    make_int4(k, j * plan.chunk, min(c, (j + 1) * plan.chunk), nch);
+                items[(size_t)s * plan.item_cap + ex[1] + j] =
+                    make_int4(k, j * plan.chunk, min(c, (j + 1) * plan.chunk),
+                              nch > 1 ? ex[2] + j : -1);          // .w = partial slot or -1
+            if (nch > 1)
+                combos[(size_t)s * plan.nblk + ex[3]] = make_int4(k, ex[2], nch, 0);
         }
         __syncthreads();
-        if (threadIdx.x == 255) { carry_c = pc + ic; carry_n = pn + in; }
+        if (threadIdx.x == 255) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) carry[i] = ex[i] + v[i];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        offsets[(size_t)s * (plan.nblk + 1) + plan.nblk] = carry_c;
-        n_items[s] = carry_n;
+        offsets[(size_t)s * (plan.nblk + 1) + plan.nblk] = carry[0];
+        n_items[2 * s] = carry[1];
+        n_items[2 * s + 1] = carry[3];             // chunked blocks to combine
     }
 }
 
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
     const int *__restrict__ offsets, const int4 *__restrict__ items,
     const int *__restrict__ n_items, const int *__restrict__ records,
-    float *__restrict__ grad_value)
+    ST *__restrict__ grad_value, float *__restrict__ partials)
 {
     constexpr int BW = 8, BH = 4, PB = 32, R = 64;
     constexpr int CH = C / 2;                          // channels per lane while summing
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const int lane = threadIdx.x;
     const int mypix = lane >> 1, half = lane & 1;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    const int n_it = n_items[s];
+    const int n_it = n_items[2 * s];
     const int lp_mask = (1 << plan.lp_bits) - 1;
 
     for (int i = lane; i < RS / 4; i += 64) {          // the zero rows
@@ -464,37 +489,92 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         }
 #undef BOXATTN_FETCH_ROWS
 #undef BOXATTN_STAGE_ROWS
-        // ---- store: one row (half) per lane; chunked blocks add their partial sums with fp32
-        //      atomics issued as full rows (two 128-byte rows per wave instruction for C=32)
-        if (item.w == 1) {
+        // ---- store.  A block handled by one item writes its rows once, in the storage type (no
+        //      zero-fill before, no conversion pass after).  A block cut into chunks writes one
+        //      fp32 partial tile per chunk; combine_partials_kernel sums them.  No float atomics
+        //      anywhere.
+        if (item.w < 0) {
             const int yy = oy + mypix / BW, xx = ox + mypix % BW;
             if (yy < lv.H && xx < lv.W) {
-                float *dst = grad_value +
-                             (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
-                             half * CH;
+                ST *dst = grad_value +
+                          (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
+                          half * CH;
 #pragma unroll
-                for (int c = 0; c < CH; c += 4)
-                    *reinterpret_cast<float4 *>(dst + c) =
-                        make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-            }
-        } else {
-            static_assert(R * RS >= PB * C * 4, "row stage doubles as the transpose tile");
-            float *t = reinterpret_cast<float *>(gstage);
+                for (int c = 0; c < CH; c += EPL) {
+                    float t[EPL];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) t[mypix * C + half * CH + c] = acc[c];
-            wave_lds_sync();
-            constexpr int LPX = (C < 64) ? C : 64;             // lanes per pixel row
-            constexpr int PXI = 64 / LPX;                      // pixels per instruction
-            for (int p0 = 0; p0 < PB; p0 += PXI) {
-                const int px = p0 + lane / LPX;
-                const int yy = oy + px / BW, xx = ox + px % BW;
-                if (yy < lv.H && xx < lv.W) {
-                    float *dst = grad_value +
-                                 (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C;
-                    for (int c = lane % LPX; c < C; c += LPX) atomic_add(dst + c, t[px * C + c]);
+                    for (int i = 0; i < EPL; ++i) t[i] = acc[c + i];
+                    VecIO<ST, EPL>::st(dst + c, t);
                 }
             }
-            wave_lds_sync();
+        } else {
+            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + mypix) * C +
+                         half * CH;
+#pragma unroll
+            for (int c = 0; c < CH; c += 4)
+                *reinterpret_cast<float4 *>(dst + c) =
+                    make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 6: sum the partial tiles of the blocks that were cut into chunks.  grid = (workers, slices),
+//    one wavefront each, looping over the slice's chunked blocks (only the coarse levels).
+// ---------------------------------------------------------------------------------------
+template <typename ST, int C>
+__global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__restrict__ combos,
+                                                              const int *__restrict__ n_items,
+                                                              const float *__restrict__ partials,
+                                                              BinPlan plan, int S, int H,
+                                                              ST *__restrict__ grad_value)
+{
+    constexpr int BW = 8, BH = 4, PB = 32, CH = C / 2, EPL = 16 / (int)sizeof(ST);
+    const int s = blockIdx.y, b = s / H, h = s % H;
+    const int n_comb = n_items[2 * s + 1];
+    const int mypix = threadIdx.x >> 1, half = threadIdx.x & 1;
+    for (int ci = blockIdx.x; ci < n_comb; ci += gridDim.x) {
+        const int4 cb = combos[(size_t)s * plan.nblk + ci];          // {block, first slot, nch}
+        BinLevel lv = plan.lv[0];
+#pragma unroll
+        for (int k = 1; k < kMaxBinLevels; ++k)
+            if (k < plan.L && cb.x >= plan.lv[k].blk0) lv = plan.lv[k];
+        const int by = (cb.x - lv.blk0) / lv.nbx, bx = (cb.x - lv.blk0) % lv.nbx;
+        const int yy = by * BH + mypix / BW, xx = bx * BW + mypix % BW;
+        if (yy >= lv.H || xx >= lv.W) continue;
+        float acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+        const float *p0 = partials + (((size_t)s * plan.pslot_cap + cb.y) * PB + mypix) * C +
+                          half * CH;
+        for (int j0 = 0; j0 < cb.z; j0 += 4) {                  // 4 partial tiles in flight
+            float4 t[4][CH / 4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 *src = reinterpret_cast<const float4 *>(
+                    p0 + (size_t)min(j0 + u, cb.z - 1) * PB * C);
+#pragma unroll
+                for (int c = 0; c < CH / 4; ++c) t[u][c] = src[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < cb.z) {
+#pragma unroll
+                    for (int c = 0; c < CH / 4; ++c) {
+                        acc[4 * c] += t[u][c].x; acc[4 * c + 1] += t[u][c].y;
+                        acc[4 * c + 2] += t[u][c].z; acc[4 * c + 3] += t[u][c].w;
+                    }
+                }
+            }
+        }
+        ST *dst = grad_value + (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
+                  half * CH;
+#pragma unroll
+        for (int c = 0; c < CH; c += EPL) {
+            float t[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) t[i] = acc[c + i];
+            VecIO<ST, EPL>::st(dst + c, t);
         }
     }
 }

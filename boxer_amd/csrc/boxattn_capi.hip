@@ -264,7 +264,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
     size_t n_items;
-    size_t part, subtot, offsets, items, records, gv_acc, total;
+    size_t part, subtot, offsets, items, combos, records, partials, total;
     int q_per_wg, n_wg;                                     // launch geometry of the bin passes
 };
 
@@ -303,6 +303,8 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     p.rec_cap = (int)rec_cap;
     p.chunk = kChunk;
     p.item_cap = (int)(blk0 + rec_cap / kChunk + 1);
+    // blocks with more than one chunk: sum of their chunk counts <= 2 * records / chunk
+    p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / kChunk) + 2, blk0 + rec_cap / kChunk + 1);
     return true;
 }
 
@@ -312,7 +314,7 @@ inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPl
     return make_plan_blocks(d, sh, ls, p);
 }
 
-inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
+inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
 {
     const size_t ns = (size_t)d.B * d.H;
     WsLayout w;
@@ -323,13 +325,14 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
                                           (kScanSub * kScanWgPerSub));
     w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
     size_t o = 0;
-    w.n_items = o; o += align_up(ns * 4);
+    w.n_items = o; o += align_up(ns * 2 * 4);
     w.part = o;    o += align_up(ns * w.n_wg * (size_t)p.nblk * 4);
     w.subtot = o;  o += align_up(ns * kScanSub * (size_t)p.nblk * 4);
     w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
     w.items = o;   o += align_up(ns * p.item_cap * 16);
+    w.combos = o;  o += align_up(ns * (size_t)p.nblk * 16);
     w.records = o; o += align_up(ns * (size_t)p.rec_cap * 4);
-    w.gv_acc = o;  o += need_gv_acc ? align_up(d.n_value() * 4) : 0;
+    w.partials = o; o += align_up(ns * (size_t)p.pslot_cap * 32 * d.C * 4);
     w.total = o;
     return w;
 }
@@ -337,7 +340,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool need_gv_acc)
 template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
-               const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, float *gv_acc,
+               const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
                float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
 {
     constexpr int BW = 8, BH = 4;
@@ -345,7 +348,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     int *part = (int *)(ws + w.part), *subtot = (int *)(ws + w.subtot);
     int *n_items = (int *)(ws + w.n_items);      // every scratch word is written before it is read
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
-    int4 *items = (int4 *)(ws + w.items);
+    int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
+    float *partials = (float *)(ws + w.partials);
     const dim3 bgrid(w.n_wg, ns);
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);   // + dump slot
     {
@@ -355,7 +359,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
                            subtot, plan);
         hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items,
-                           n_items, plan);
+                           combos, n_items, plan);
         hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
                            d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
     }
@@ -371,16 +375,21 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         else
             hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
                                0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
-                               d.S, d.H, d.L, d.Lq, d.P, gv_acc, grad_loc, grad_sp, grad_lv, n_qh);
+                               d.S, d.H, d.L, d.Lq, d.P, (float *)nullptr, grad_loc, grad_sp, grad_lv,
+                               n_qh);
     }
     // persistent single-wave workgroups: ~13 per CU fit in LDS.  The kernel maps workgroups to
     // (slice, worker) itself (XCD affinity); it needs workers * ceil(ns/8)*8 workgroups.
     const int ns8 = (ns + 7) / 8 * 8;
     const int wg_per_slice = std::max(1, (256 * 13 + ns8 - 1) / ns8);
-    ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
-    hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns8),
-                       dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P,
-                       offsets, items, n_items, records, gv_acc);
+    {
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
+        hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns8),
+                           dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
+                           d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
+    }
+    hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
+                       n_items, partials, plan, d.S, d.H, grad_value);
     return finish();
 }
 
@@ -404,7 +413,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   aligned(workspace, 256) && aligned(grad_value, 16);
     WsLayout w{};
     if (binned) {
-        w = ws_layout(d, plan, kBf16);
+        w = ws_layout(d, plan);
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
@@ -423,31 +432,20 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         !value || (INST && (!w_lv || !grad_mask || !grad_lv)))
         return (int)hipErrorInvalidValue;
     char *ws = (char *)workspace;
-    float *gv_acc;
-    if constexpr (kBf16) gv_acc = (float *)(ws + w.gv_acc);
-    else gv_acc = grad_value;
-    hipError_t e = hipMemsetAsync(gv_acc, 0, nv * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
     int rc = 0;
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
-                                      d, plan, w, ws, gv_acc, grad_loc, grad_sp, grad_lv, st);  \
+                                      d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
+                                      st);                                                      \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
         BOXATTN_BINNED_CASE(16)
 #undef BOXATTN_BINNED_CASE
     }
-    if (rc) return rc;
-    if constexpr (kBf16) {
-        const int blocks = (int)std::min<size_t>((nv / 4 + 255) / 256 + 1, 256 * 16);
-        hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, st, gv_acc,
-                           grad_value, nv);
-        return finish();
-    }
-    return 0;
+    return rc;
 }
 
 }  // namespace
@@ -462,7 +460,7 @@ size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int 
     const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
     BinPlan plan;
     if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
-    return std::max(fallback, ws_layout(d, plan, is_bf16 != 0).total);
+    return std::max(fallback, ws_layout(d, plan).total);
 }
 
 int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,

@@ -72,20 +72,19 @@ def _chunk_assert(batch, im2col_step):
             "batch(%d) must divide im2col_step(%d)" % (batch, step)
 
 
-_HOST_TABLES = {}          # (data_ptr, version, numel, device) -> numpy int64 copy
-
-
 def _host_table(t):
-    """Host copy of a small int64 device table (level shapes / start indices), cached per
-    tensor so that only the first call with a given tensor synchronises."""
-    key = (t.data_ptr(), t._version, t.numel(), t.device.index)
-    got = _HOST_TABLES.get(key)
-    if got is None:
-        if len(_HOST_TABLES) > 64:
-            _HOST_TABLES.clear()
-        got = t.detach().cpu().contiguous().numpy().copy()
-        _HOST_TABLES[key] = got
-    return got
+    """Host copy of a small int64 device table (level shapes / start indices).  The copy is
+    cached ON the tensor object together with its version counter, so only the first call with
+    a given tensor synchronises (BoxeR hands the same two tensors to every layer of a step).
+    Keying a global cache by data_ptr would be wrong: a freed tensor's address gets reused."""
+    cached = getattr(t, "_boxattn_host", None)
+    if cached is None or cached[0] != t._version:
+        cached = (t._version, t.detach().cpu().contiguous().numpy().copy())
+        try:
+            t._boxattn_host = cached
+        except Exception:          # objects that refuse attributes: just do not cache
+            pass
+    return cached[1]
 
 
 def _backward_with_workspace(name, value, shapes, lsi, dims, args):
