@@ -306,10 +306,11 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         if constexpr (INST) reinterpret_cast<int *>(&mstage[R * RS])[i] = 0;
     }
 
-    // Static round-robin over the slice's items, heaviest first.  A dynamic queue was slower
-    // both ways it was tried: with the 16 queue heads in one cache line every dequeue of the
-    // chip serialised on that line (13 k atomics = 160 us), and with padded heads the dequeue
-    // latency still cost 10 % (184 vs 167 us).
+    // Items are taken heaviest first.  The launch provides one workgroup per potential item, so
+    // this loop normally runs once and the hardware workgroup dispatcher does the load
+    // balancing.  (A software queue was slower both ways it was tried: with the 16 queue heads
+    // in one cache line every dequeue of the chip serialised on that line -- 13 k atomics =
+    // 160 us --, and with padded heads the dequeue round trip still cost 10 %.)
     for (int it = worker; it < n_it; it += workers) {
         // coarse levels sit at the end of the list and carry the long chunked items: take
         // them first so the tail of the kernel is made of short items
