@@ -256,6 +256,50 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 }
 
 
+// One helper stream + two events per device, created on first use and kept for the life of
+// the process (no device memory).  fork: side waits for everything queued on `main` so far;
+// join: `main` waits for everything queued on the side stream.
+struct SideStream {
+    static constexpr int kMaxDev = 16;
+    struct PerDev { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    static PerDev &slot()
+    {
+        static PerDev devs[kMaxDev];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        PerDev &p = devs[dev % kMaxDev];
+        if (!p.s) {
+            // lowest priority: the side kernel fills what the main chain leaves idle
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&p.s, hipStreamNonBlocking, least) != hipSuccess)
+                p.s = nullptr;
+            if (p.s && (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&p.join, hipEventDisableTiming) != hipSuccess))
+                p.s = nullptr;
+        }
+        return p;
+    }
+    hipStream_t main_, side_;
+    PerDev *p_;
+    explicit SideStream(hipStream_t main) : main_(main), side_(main), p_(&slot())
+    {
+        if (!p_->s || g_variant == 4) return;                 // no helper: stay on the main stream
+        if (hipEventRecord(p_->fork, main_) == hipSuccess &&
+            hipStreamWaitEvent(p_->s, p_->fork, 0) == hipSuccess)
+            side_ = p_->s;
+    }
+    hipStream_t stream() const { return side_; }
+    void join()
+    {
+        if (side_ == main_) return;
+        (void)hipEventRecord(p_->join, side_);
+        (void)hipStreamWaitEvent(main_, p_->join, 0);
+        side_ = main_;
+    }
+    ~SideStream() { join(); }
+};
+
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
 constexpr int kChunk = 1024;          // records per work item
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
@@ -350,6 +394,11 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     float *partials = (float *)(ws + w.partials);
+    // grad_loc / grad_weight (query-major gathers) do not depend on the binning: run them on the
+    // library's helper stream, concurrently with the bin passes and the accumulate kernel, which
+    // is latency-bound at ~13 waves per CU and leaves issue slots free.  Fork/join with events,
+    // so the caller still sees one in-order stream (also valid under stream capture).
+    SideStream side(st);
     const dim3 bgrid(w.n_wg, ns);
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);   // + dump slot
     {
@@ -363,7 +412,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
                            d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
     }
-    {   // grad_loc / grad_weight, query-major, no scatter
+    {
+        hipStream_t st = side.stream();                       // shadows: launch on the side stream
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
         const size_t n_qh = d.n_qh();
         const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
@@ -393,6 +443,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     }
     hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
                        n_items, partials, plan, d.S, d.H, grad_value);
+    side.join();
     return finish();
 }
 
@@ -409,7 +460,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     if (!d.valid()) return (int)hipErrorInvalidValue;
     BinPlan plan;
     const size_t nv = d.n_value();
-    bool binned = (g_variant == 0 || g_variant == 3) && workspace && nv && d.n_qh() &&
+    bool binned = (g_variant == 0 || g_variant == 3 || g_variant == 4) && workspace && nv && d.n_qh() &&
                   make_plan(d, shapes_host, lsi_host, plan) &&
                   fast_ok<ST>(d, value, loc, grad_out,
                               INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
