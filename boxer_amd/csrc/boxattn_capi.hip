@@ -59,6 +59,14 @@ bool fast_ok(const Dims &d, const void *value, const void *loc, const void *a, c
            aligned(c, va);
 }
 
+// How many workgroups should share the point tiles of a (query, head) pair: aim at ~4096
+// workgroups when the query dimension alone gives fewer than 1024.
+inline int point_split(int blocks, int tiles)
+{
+    if (blocks >= 1024 || tiles < 2) return 1;
+    return std::max(1, std::min(tiles, (4096 + blocks - 1) / blocks));
+}
+
 inline int finish()
 {
     return (int)hipGetLastError();
@@ -140,13 +148,22 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
             const size_t vbytes = d.n_value() * sizeof(ST);
             const bool gen2 = g_variant != 2 && vbytes < kOobOffset;   // buffer-load kernels
+            // instance attention with few queries and many points: split the points of a pair
+            // over several workgroups (fp32 only: partial outs are combined with atomics)
+            int fsplit = 1;
+            if (INST && gen2 && std::is_same<ST, float>::value)
+                fsplit = point_split(blocks, (d.P + G - 1) / G);
+            if (fsplit > 1) {
+                hipError_t e = hipMemsetAsync(out, 0, n_qh * d.C * sizeof(ST), st);
+                if (e != hipSuccess) return (int)e;
+            }
             ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
         if (gen2)                                                                             \
             hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, (sizeof(ST) == 2 && GG >= 4) ? 4 : GG>), \
-                               dim3(blocks), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
-                               w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh,               \
+                               dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, \
+                               w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh,         \
                                (unsigned)vbytes);                                             \
         else                                                                                  \
             hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, \
@@ -419,9 +436,11 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
         const size_t vbytes = d.n_value() * sizeof(ST);
         if (vbytes < kOobOffset)
-            hipLaunchKernelGGL((pointgrad2_kernel<ST, G, INST>), dim3(blocks), dim3(256), 0, st,
-                               value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d.S, d.H,
-                               d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv, n_qh, (unsigned)vbytes);
+            hipLaunchKernelGGL((pointgrad2_kernel<ST, G, INST>),
+                               dim3(blocks, point_split(blocks, (d.L * d.P + G - 1) / G)),
+                               dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out,
+                               grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,
+                               n_qh, (unsigned)vbytes);
         else
             hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
                                0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
         }
     } else {
         ST *mk = mask + bq * P * HC + (size_t)h * C + slot * VEC;
-        for (int p0 = 0; p0 < P; p0 += G) {
+        // few queries x many points (decoder, 14x14 grids): gridDim.y workgroups share the
+        // point tiles of a (query, head) pair; out is then accumulated with atomics
+        const int tiles = (P + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int p_begin = (int)blockIdx.y * tps * G, p_end = min(P, p_begin + tps * G);
+        for (int p0 = p_begin; p0 < p_end; p0 += G) {
             float macc[G][VEC];
 #pragma unroll
             for (int t = 0; t < G; ++t)
@@ -191,7 +195,16 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                 if (active && p0 + t < P) VecIO<ST, VEC>::st(mk + (size_t)(p0 + t) * HC, macc[t]);
         }
     }
-    if (active) VecIO<ST, VEC>::st(out + qh * C + slot * VEC, acc);
+    if (active) {
+        if constexpr (INST && std::is_same<ST, float>::value) {
+            if (gridDim.y > 1) {                   // split points: out was zero-filled by the host
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) atomic_add(out + qh * C + slot * VEC + c, acc[c]);
+                return;
+            }
+        }
+        VecIO<ST, VEC>::st(out + qh * C + slot * VEC, acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -235,7 +248,10 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     float g[VEC];
     VecIO<ST, VEC>::ld(grad_out + qh * C + slot * VEC, g);
 
-    for (int t0 = 0; t0 < LP; t0 += G) {
+    // gridDim.y workgroups share the point tiles of a pair (few queries x many points)
+    const int tiles = (LP + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_begin = (int)blockIdx.y * tps * G, t_end = min(LP, t_begin + tps * G);
+    for (int t0 = t_begin; t0 < t_end; t0 += G) {
         // ---- step A (the lane keeps its point's geometry in registers for the finish)
         const int lp = t0 + slot;
         const bool have = lp < LP;

@@ -123,6 +123,10 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
  * B*S*H*C floats).  Only float32 and bfloat16 exist here; float64 uses the plain backward.
+ * The binned path uses no float atomics and no zero-fill; it runs its point-gradient kernel on
+ * a library-owned low-priority helper stream (one per device, created on first use) that is
+ * forked from and joined back into `stream` with events, so the caller still sees one in-order
+ * stream (valid under stream capture).
  */
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                                    const int64_t *shapes_host, const int64_t *lsi_host);
@@ -155,8 +159,11 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
 /*
  * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):
  *   0 = automatic choice (default), 1 = force the generic kernels (any C),
- *   2 = fast atomic kernels (error if the shape does not qualify; never the binned backward),
- *   3 = binned backward required (error if not eligible).  Returns the previous value.
+ *   2 = first-generation fast kernels with fp atomics (error if the shape does not qualify;
+ *       never the binned backward),
+ *   3 = binned backward required (error if not eligible),
+ *   4 = like 0 but the backward runs on one stream (no helper stream; used for per-kernel
+ *       timing).  Returns the previous value.
  */
 int boxattn_set_variant(int variant);
 
