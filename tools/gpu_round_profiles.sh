@@ -6,6 +6,8 @@ for cfg in "bf16_model" "bf16_model_serial --variant 4" "fp32_model --dtype fp32
   set -- $cfg; tag=$1; shift
   bash tools/gpu_prof.sh $tag "$@" > /dev/null 2>&1
   python tools/rocpd_stats.py gpurun_out/prof_$tag/trace_results.db | head -12 > gpurun_out/kernel_stats_$tag.txt
+  rm -rf gpurun_out/prof_$tag
   bash tools/gpu_traffic.sh $tag "$@" > gpurun_out/traffic_$tag.txt 2>&1
+  rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
 done
 head -6 gpurun_out/kernel_stats_bf16_model.txt
