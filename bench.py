@@ -158,16 +158,16 @@ def make_step(inp):
     v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
                                                   "grad_out"))
     if inp["kind"] == "box":
-        def step():
-            out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
-            grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+        def step():      # training step: the forward also prepares the backward's plan
+            out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+            grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
             return out, grads
     else:
         lw, gm = inp["level_w"], inp["grad_mask"]
 
         def step():
-            out = ops.instance_attn_forward(v, sh, ls, loc, attn, lw, 64)
-            grads = ops.instance_attn_backward(v, sh, ls, loc, attn, lw, go, gm, 64)
+            out, plan = ops.instance_attn_forward_train(v, sh, ls, loc, attn, lw, 64)
+            grads = ops.instance_attn_backward(v, sh, ls, loc, attn, lw, go, gm, 64, plan=plan)
             return out, grads
     return step
 

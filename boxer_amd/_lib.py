@@ -31,14 +31,18 @@ _SIGNATURES = {
 }
 _WS_SIGNATURES = {
     # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, stream
-    "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _vp],
-    "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _i, _vp],
+    "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _i, _vp],
+    # forward args + shapes_host, lsi_host, workspace, workspace_bytes, int *plan_built, stream
+    "boxattn_fwd_train": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    "instattn_fwd_train": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
+                                                          _vp],
 }
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def hipcc_path():

@@ -398,16 +398,38 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
     return w;
 }
 
-template <typename ST, int G, bool INST>
-int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
-               const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
-               const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
-               float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
+// Binning passes (count, two scans, fill) of the binned backward into the workspace.  They only
+// read the sampling locations, so the training forward can run them ahead of the backward.
+inline void launch_binning(const float *loc, const Dims &d, const BinPlan &plan, const WsLayout &w,
+                           char *ws, hipStream_t st)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
     int *part = (int *)(ws + w.part), *subtot = (int *)(ws + w.subtot);
     int *n_items = (int *)(ws + w.n_items);      // every scratch word is written before it is read
+    int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
+    int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
+    const dim3 bgrid(w.n_wg, ns);
+    const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
+    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H, d.Lq,
+                       d.P, w.q_per_wg, part, subtot, offsets, records);
+    hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
+                       subtot, plan);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items, combos,
+                       n_items, plan);
+    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H, d.Lq,
+                       d.P, w.q_per_wg, part, subtot, offsets, records);
+}
+
+template <typename ST, int G, bool INST>
+int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+               const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
+               const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
+               float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st)
+{
+    const int ns = d.B * d.H;
+    int *n_items = (int *)(ws + w.n_items);
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     float *partials = (float *)(ws + w.partials);
@@ -416,19 +438,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // is latency-bound at ~13 waves per CU and leaves issue slots free.  Fork/join with events,
     // so the caller still sees one in-order stream (also valid under stream capture).
     SideStream side(st);
-    const dim3 bgrid(w.n_wg, ns);
-    const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);   // + dump slot
-    {
-        ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
-        hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                           d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
-        hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
-                           subtot, plan);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items,
-                           combos, n_items, plan);
-        hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H,
-                           d.Lq, d.P, w.q_per_wg, part, subtot, offsets, records);
-    }
+    if (!plan_ready) launch_binning(loc, d, plan, w, ws, st);
     {
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
@@ -473,7 +483,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                  size_t workspace_bytes, hipStream_t st)
+                  size_t workspace_bytes, bool plan_ready, hipStream_t st)
 {
     constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
     if (!d.valid()) return (int)hipErrorInvalidValue;
@@ -490,7 +500,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
-        if (g_variant == 3) return (int)hipErrorInvalidValue;
+        if (g_variant == 3 || plan_ready) return (int)hipErrorInvalidValue;
         float *acc = nullptr;
         if constexpr (kBf16) {
             if (!workspace || workspace_bytes < nv * sizeof(float)) return (int)hipErrorInvalidValue;
@@ -511,7 +521,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
-                                      st);                                                      \
+                                      plan_ready, st);                                          \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -521,9 +531,83 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     return rc;
 }
 
+// Training forward: the forward kernel on `stream`, and on the helper stream (concurrently) the
+// binning passes of the backward, which only depend on the sampling locations.  The workspace
+// then carries the plan to the *_bwd_ws_* call (plan_ready = 1).
+template <typename ST, bool INST>
+int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                     const float *w_sp, const float *w_lv, const Dims &d, ST *out, ST *mask,
+                     const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                     size_t workspace_bytes, int *plan_built, hipStream_t st)
+{
+    if (plan_built) *plan_built = 0;
+    BinPlan plan;
+    bool ok = (g_variant == 0 || g_variant == 3 || g_variant == 4) && workspace && d.valid() &&
+              d.n_value() && d.n_qh() && make_plan(d, shapes_host, lsi_host, plan) &&
+              aligned(workspace, 256) && aligned(loc, 8);
+    WsLayout w{};
+    if (ok) {
+        w = ws_layout(d, plan);
+        ok = workspace_bytes >= w.total;
+    }
+    if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
+    SideStream side(st);
+    launch_binning(loc, d, plan, w, (char *)workspace, side.stream());
+    const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
+    side.join();
+    if (rc == 0 && plan_built) *plan_built = 1;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                          int Lq, int P, float *out, const int64_t *shapes_host,
+                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                          int *plan_built, void *stream)
+{
+    return launch_fwd_train<float, false>(value, shapes, lsi, loc, attn, nullptr,
+                                          Dims{B, S, H, C, L, Lq, P}, out, nullptr, shapes_host,
+                                          lsi_host, workspace, workspace_bytes, plan_built,
+                                          (hipStream_t)stream);
+}
+int boxattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                           const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                           int Lq, int P, uint16_t *out, const int64_t *shapes_host,
+                           const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                           int *plan_built, void *stream)
+{
+    return launch_fwd_train<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr,
+                                           Dims{B, S, H, C, L, Lq, P}, out, nullptr, shapes_host,
+                                           lsi_host, workspace, workspace_bytes, plan_built,
+                                           (hipStream_t)stream);
+}
+int instattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                           const float *loc, const float *spatial_w, const float *level_w, int B,
+                           int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
+                           const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                           size_t workspace_bytes, int *plan_built, void *stream)
+{
+    return launch_fwd_train<float, true>(value, shapes, lsi, loc, spatial_w, level_w,
+                                         Dims{B, S, H, C, L, Lq, P}, out, mask_out, shapes_host,
+                                         lsi_host, workspace, workspace_bytes, plan_built,
+                                         (hipStream_t)stream);
+}
+int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *loc, const float *spatial_w, const float *level_w, int B,
+                            int S, int H, int C, int L, int Lq, int P, uint16_t *out,
+                            uint16_t *mask_out, const int64_t *shapes_host,
+                            const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                            int *plan_built, void *stream)
+{
+    return launch_fwd_train<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w,
+                                          Dims{B, S, H, C, L, Lq, P}, out, mask_out, shapes_host,
+                                          lsi_host, workspace, workspace_bytes, plan_built,
+                                          (hipStream_t)stream);
+}
 
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                                    const int64_t *shapes_host, const int64_t *lsi_host)
@@ -540,24 +624,24 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        const float *loc, const float *attn, const float *grad_out, int B, int S,
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
-                       void *workspace, size_t workspace_bytes, void *stream)
+                       void *workspace, size_t workspace_bytes, int plan_ready, void *stream)
 {
     return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
                                        Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                       workspace_bytes, (hipStream_t)stream);
+                                       workspace_bytes, plan_ready != 0, (hipStream_t)stream);
 }
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        void *stream)
+                        int plan_ready, void *stream)
 {
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
                                         Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                         grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                        workspace_bytes, (hipStream_t)stream);
+                                        workspace_bytes, plan_ready != 0, (hipStream_t)stream);
 }
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
@@ -565,12 +649,12 @@ int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        void *stream)
+                        int plan_ready, void *stream)
 {
     return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
                                       grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                       grad_spatial_w, grad_level_w, shapes_host, lsi_host,
-                                      workspace, workspace_bytes, (hipStream_t)stream);
+                                      workspace, workspace_bytes, plan_ready != 0, (hipStream_t)stream);
 }
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
@@ -578,12 +662,12 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         void *stream)
+                         int plan_ready, void *stream)
 {
     return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
                                        grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                        grad_spatial_w, grad_level_w, shapes_host, lsi_host,
-                                       workspace, workspace_bytes, (hipStream_t)stream);
+                                       workspace, workspace_bytes, plan_ready != 0, (hipStream_t)stream);
 }
 
 

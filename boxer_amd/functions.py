@@ -19,12 +19,26 @@ from torch.autograd.function import once_differentiable
 from . import ops
 
 
+def _box_forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+    """Training forward (also prepares the backward's plan) when a gradient will be asked for."""
+    if any(ctx.needs_input_grad):
+        return ops.box_attn_forward_train(value, shapes, lsi, loc, attn, im2col_step)
+    return ops.box_attn_forward(value, shapes, lsi, loc, attn, im2col_step), None
+
+
+def _inst_forward(ctx, value, shapes, lsi, loc, sw, lw, im2col_step):
+    if any(ctx.needs_input_grad):
+        return ops.instance_attn_forward_train(value, shapes, lsi, loc, sw, lw, im2col_step)
+    return ops.instance_attn_forward(value, shapes, lsi, loc, sw, lw, im2col_step), None
+
+
 def _box_backward(ctx, grad_output):
     if not grad_output.is_contiguous():
         grad_output = grad_output.contiguous()
     value, shapes, lsi, loc, attn = ctx.saved_tensors
     grad_value, grad_loc, grad_attn = ops.box_attn_backward(
-        value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step)
+        value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step, plan=ctx.plan)
+    ctx.plan = None
     return grad_value, None, None, grad_loc.to(ctx.loc_dtype), grad_attn.to(ctx.attn_dtype), None
 
 
@@ -35,7 +49,9 @@ def _inst_backward(ctx, grad_output, grad_mask_output):
         grad_mask_output = grad_mask_output.contiguous()
     value, shapes, lsi, loc, sw, lw = ctx.saved_tensors
     grad_value, grad_loc, grad_sw, grad_lw = ops.instance_attn_backward(
-        value, shapes, lsi, loc, sw, lw, grad_output, grad_mask_output, ctx.im2col_step)
+        value, shapes, lsi, loc, sw, lw, grad_output, grad_mask_output, ctx.im2col_step,
+        plan=ctx.plan)
+    ctx.plan = None
     return (grad_value, None, None, grad_loc.to(ctx.loc_dtype), grad_sw.to(ctx.w_dtype),
             grad_lw.to(ctx.w_dtype), None, None)
 
@@ -47,8 +63,9 @@ class BoxAttnFunction(Function):
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
         ctx.loc_dtype, ctx.attn_dtype = sampling_locations.dtype, attention_weights.dtype
-        output = ops.box_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                      sampling_locations, attention_weights, im2col_step)
+        output, ctx.plan = _box_forward(ctx, value, value_spatial_shapes,
+                                        value_level_start_index, sampling_locations,
+                                        attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -67,8 +84,8 @@ class InstanceAttnFunction(Function):
                 spatial_attention_weights, level_attention_weights, mask_size, im2col_step):
         ctx.im2col_step = im2col_step
         ctx.loc_dtype, ctx.w_dtype = sampling_locations.dtype, spatial_attention_weights.dtype
-        output, mask_output = ops.instance_attn_forward(
-            value, value_spatial_shapes, value_level_start_index, sampling_locations,
+        (output, mask_output), ctx.plan = _inst_forward(
+            ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
             spatial_attention_weights, level_attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, spatial_attention_weights,
@@ -98,8 +115,8 @@ class BoxAttnBF16Function(Function):
         ctx.loc_dtype, ctx.attn_dtype = sampling_locations.dtype, attention_weights.dtype
         ctx.value_dtype = value.dtype
         value, loc, attn = _to_bf16_args(value, sampling_locations, attention_weights)
-        output = ops.box_attn_forward(value, value_spatial_shapes, value_level_start_index, loc,
-                                      attn, im2col_step)
+        output, ctx.plan = _box_forward(ctx, value, value_spatial_shapes,
+                                        value_level_start_index, loc, attn, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, attn)
         return output
 
@@ -119,8 +136,8 @@ class InstanceAttnBF16Function(Function):
         ctx.value_dtype = value.dtype
         value, loc, sw, lw = _to_bf16_args(value, sampling_locations, spatial_attention_weights,
                                            level_attention_weights)
-        output, mask_output = ops.instance_attn_forward(
-            value, value_spatial_shapes, value_level_start_index, loc, sw, lw, im2col_step)
+        (output, mask_output), ctx.plan = _inst_forward(
+            ctx, value, value_spatial_shapes, value_level_start_index, loc, sw, lw, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, loc, sw, lw)
         b, l, _, c = mask_output.shape
         return output, mask_output.view(b, l, mask_size, mask_size, c)

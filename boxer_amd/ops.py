@@ -87,18 +87,60 @@ def _host_table(t):
     return cached[1]
 
 
-def _backward_with_workspace(name, value, shapes, lsi, dims, args):
-    """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
+class BackwardPlan:
+    """Opaque hand-over from a training forward to the matching backward: the scratch tensor in
+    which the forward already binned the sample points (the binning only depends on the sampling
+    locations, so it runs concurrently with the forward kernel), plus what it is valid for."""
+
+    __slots__ = ("ws", "key")
+
+    def __init__(self, ws, key):
+        self.ws, self.key = ws, key
+
+
+def _plan_key(dims, loc):
+    return (tuple(dims), loc.data_ptr(), loc._version, loc.device.index)
+
+
+def _workspace(value, shapes, lsi, dims):
     lib = _lib.load()
     sh, ls = _host_table(shapes), _host_table(lsi)
     is_bf16 = int(value.dtype == torch.bfloat16)
     nbytes = lib.boxattn_bwd_workspace_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)
     ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=value.device)
+    return ws, sh, ls
+
+
+def _forward_train(name, value, shapes, lsi, loc, dims, args):
+    """*_fwd_train_*: forward + (when the binned backward applies) the backward's plan."""
+    import ctypes
+    lib = _lib.load()
+    ws, sh, ls = _workspace(value, shapes, lsi, dims)
+    built = ctypes.c_int(0)
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
-                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(), stream)
+                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(),
+                ctypes.addressof(built), stream)
+    if rc != 0:
+        raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
+    return BackwardPlan(ws, _plan_key(dims, loc)) if built.value else None
+
+
+def _backward_with_workspace(name, value, shapes, lsi, loc, dims, args, plan=None):
+    """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
+    lib = _lib.load()
+    ready = int(plan is not None and plan.key == _plan_key(dims, loc))
+    if ready:
+        ws, sh, ls = plan.ws, _host_table(shapes), _host_table(lsi)
+    else:
+        ws, sh, ls = _workspace(value, shapes, lsi, dims)
+    fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream(value.device).cuda_stream
+        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
+                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(), ready, stream)
     if rc != 0:
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
 
@@ -124,8 +166,26 @@ def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, att
     return out
 
 
+def box_attn_forward_train(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """Forward for training: -> (output, plan).  ``plan`` (or None) goes to
+    ``box_attn_backward(..., plan=plan)``: the forward already binned the sample points for the
+    backward, concurrently with the forward kernel.  Not part of the reference API."""
+    dims, loc, (attn,), _ = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
+                                     [attn_weight])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
+    if value.dtype == torch.float64:
+        _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
+        return out, None
+    plan = _forward_train("boxattn_fwd_train", value, spatial_shapes, level_start_index, loc, dims,
+                          [value, spatial_shapes, level_start_index, loc, attn, *dims, out])
+    return out, plan
+
+
 def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                      grad_output, im2col_step):
+                      grad_output, im2col_step, plan=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight] (box_attn.cu:74-135).
     For bfloat16 ``value`` the location / weight gradients are float32."""
     dims, loc, (attn,), cdt = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
@@ -142,8 +202,8 @@ def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, at
     if value.dtype == torch.float64:
         _call("boxattn_bwd", value, *args)
     else:
-        _backward_with_workspace("boxattn_bwd_ws", value, spatial_shapes, level_start_index,
-                                 dims, args)
+        _backward_with_workspace("boxattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
+                                 dims, args, plan)
     return [grad_value, grad_loc, grad_attn]
 
 
@@ -161,9 +221,27 @@ def instance_attn_forward(value, spatial_shapes, level_start_index, sampling_loc
     return [out, mask]
 
 
+def instance_attn_forward_train(value, spatial_shapes, level_start_index, sampling_loc,
+                                spatial_attn_weight, level_attn_weight, im2col_step):
+    """-> ([output, mask_output], plan); see box_attn_forward_train."""
+    dims, loc, (sw, lw), _ = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
+                                      [spatial_attn_weight, level_attn_weight])
+    B, S, H, C, L, Lq, P = dims
+    _chunk_assert(B, im2col_step)
+    out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
+    mask = torch.empty((B, Lq, P, H * C), dtype=value.dtype, device=value.device)
+    args = [value, spatial_shapes, level_start_index, loc, sw, lw, *dims, out, mask]
+    if value.dtype == torch.float64:
+        _call("instattn_fwd", value, *args)
+        return [out, mask], None
+    plan = _forward_train("instattn_fwd_train", value, spatial_shapes, level_start_index, loc,
+                          dims, args)
+    return [out, mask], plan
+
+
 def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_loc,
                            spatial_attn_weight, level_attn_weight, grad_output,
-                           grad_mask_output, im2col_step):
+                           grad_mask_output, im2col_step, plan=None):
     """-> [grad_value, grad_sampling_loc, grad_spatial_attn_weight, grad_level_attn_weight]
     (instance_attn.cu:85-157)."""
     dims, loc, (sw, lw), cdt = _prepare(
@@ -183,6 +261,6 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
     if value.dtype == torch.float64:
         _call("instattn_bwd", value, *args)
     else:
-        _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index,
-                                 dims, args)
+        _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
+                                 dims, args, plan)
     return [grad_value, grad_loc, grad_sw, grad_lw]

@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 3
+#define BOXATTN_ABI_VERSION 4
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -123,6 +123,9 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
  * B*S*H*C floats).  Only float32 and bfloat16 exist here; float64 uses the plain backward.
+ * plan_ready: 0 = the call bins the sample points itself; 1 = `workspace` already holds the plan
+ * that a *_fwd_train_* call built for the SAME sampling locations and dimensions (the call then
+ * fails with hipErrorInvalidValue if the binned algorithm does not apply).
  * The binned path uses no float atomics and no zero-fill; it runs its point-gradient kernel on
  * a library-owned low-priority helper stream (one per device, created on first use) that is
  * forked from and joined back into `stream` with events, so the caller still sees one in-order
@@ -134,27 +137,59 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        const float *loc, const float *attn, const float *grad_out, int B, int S,
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       void *workspace, size_t workspace_bytes, int plan_ready,
+        void *stream);
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
-                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
+        void *stream);
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
                         const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
-                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
+        void *stream);
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
                          const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
-                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         void *stream);
+                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
+        void *stream);
+
+/*
+ * ---- training forward: forward + backward plan ----------------------------------------------
+ * Same as the plain forward, and additionally (when the binned backward applies) runs the
+ * binning passes of the backward -- they only depend on the sampling locations -- on the
+ * library's helper stream, concurrently with the forward kernel, into `workspace`
+ * (boxattn_bwd_workspace_bytes bytes; it must stay untouched until the matching *_bwd_ws_*
+ * call, which is then given plan_ready = 1).  *plan_built is set to 1 if the plan was built,
+ * 0 if the call was just a plain forward (shape not eligible / workspace too small).
+ */
+int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                          int Lq, int P, float *out, const int64_t *shapes_host,
+                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                          int *plan_built, void *stream);
+int boxattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                           const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                           int Lq, int P, uint16_t *out, const int64_t *shapes_host,
+                           const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                           int *plan_built, void *stream);
+int instattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                           const float *loc, const float *spatial_w, const float *level_w, int B,
+                           int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
+                           const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                           size_t workspace_bytes, int *plan_built, void *stream);
+int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *loc, const float *spatial_w, const float *level_w, int B,
+                            int S, int H, int C, int L, int Lq, int P, uint16_t *out,
+                            uint16_t *mask_out, const int64_t *shapes_host,
+                            const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                            int *plan_built, void *stream);
 
 /*
  * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):

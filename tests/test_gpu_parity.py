@@ -497,3 +497,61 @@ def test_binned_backward_run_to_run(dtype):
         scale = max(1.0, first[0].float().abs().max().item())
         tol = 1e-6 if dtype == torch.float32 else 8e-3        # bf16: one output ulp
         assert (first[0].float() - again[0].float()).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_forward_plan(dtype):
+    """box_attn_forward_train bins the sample points for the backward while the forward kernel
+    runs; the backward that receives the plan must give the same gradients, and a plan that no
+    longer matches the locations (in-place update) must be ignored, not trusted."""
+    from boxer_amd import ops
+    g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=41, lo=-0.2, hi=1.2)
+    cdt = _cdt(dtype)
+    value, loc, attn = dev(g["value"], dtype), dev(g["loc"], cdt), dev(g["attn"], cdt)
+    shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], dtype)
+    want_out = oc.box_attn_forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"])
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    out, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
+    assert plan is not None
+    close(out, want_out, dtype, "out")
+    gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)
+    close(gv, want[0], dtype, "grad_value (plan)")
+    close(gl, want[1], torch.float32, "grad_loc (plan)", ignore=g["on_edge"])
+    close(ga, want[2], torch.float32, "grad_attn (plan)")
+    # stale plan: move every location, keep the tensor object
+    loc.mul_(0.5).add_(0.25)
+    g2 = dict(g, loc=(g["loc"].astype(np.float32) * np.float32(0.5) + np.float32(0.25)).astype(np.float64))
+    want2 = oc.box_attn_backward(g2["value"], g2["shapes"], g2["lsi"], g2["loc"], g2["attn"],
+                                 g2["grad_out"])
+    gv2, _, _ = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)
+    close(gv2, want2[0], dtype, "grad_value (stale plan ignored)")
+
+
+def test_functions_use_the_plan_and_match():
+    from boxer_amd import BoxAttnFunction, InstanceAttnFunction
+    g = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 200, 4, seed=43)
+    shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
+    v = dev(g["value"], torch.float32).requires_grad_()
+    l = dev(g["loc"], torch.float32).requires_grad_()
+    a = dev(g["attn"], torch.float32).requires_grad_()
+    out = BoxAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    out.backward(dev(g["grad_out"], torch.float32))
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    close(v.grad, want[0], torch.float32, "grad_value")
+    close(a.grad, want[2], torch.float32, "grad_attn")
+    # no gradient requested -> plain forward, no plan work
+    with torch.no_grad():
+        out2 = BoxAttnFunction.apply(v.detach(), shapes, lsi, l.detach(), a.detach(), 64)
+    assert torch.equal(out, out2)
+    sw = dev(g["spatial_w"], torch.float32).view(2, 200, 8, 4, 2, 2).requires_grad_()
+    lw = dev(g["level_w"], torch.float32).view(2, 200, 8, 4, 2, 2).requires_grad_()
+    v.grad = None
+    o, m = InstanceAttnFunction.apply(v, shapes, lsi, l, sw, lw, 2, 64)
+    torch.autograd.backward([o, m], [dev(g["grad_out"], torch.float32),
+                                     dev(g["grad_mask"], torch.float32).view_as(m)])
+    wi = oc.instance_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["spatial_w"],
+                                   g["level_w"], g["grad_out"], g["grad_mask"])
+    close(v.grad, wi[0], torch.float32, "instance grad_value")
+    close(sw.grad, wi[2].reshape(sw.shape), torch.float32, "instance grad_spatial")
