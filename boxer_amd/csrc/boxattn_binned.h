@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
 //    grid = (waves per slice, slices); waves are persistent and pull items from the slice's
 //    queue.  A block is 8x4 pixels; in the summation phase lane = (pixel, channel half).
 // ---------------------------------------------------------------------------------------
-template <typename ST, int C, bool INST>
+template <typename ST, int C, bool INST, int RPL = 1>
 __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask,
     const float *__restrict__ loc, const float *__restrict__ w_sp,
@@ -266,10 +266,14 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const int *__restrict__ n_items, const int *__restrict__ records,
     ST *__restrict__ grad_value, float *__restrict__ partials)
 {
-    constexpr int BW = 8, BH = 4, PB = 32, R = 64;
+    constexpr int BW = 8, BH = 4, PB = 32;
+    constexpr int R = 64 * RPL;                        // records per round, RPL per lane
     constexpr int CH = C / 2;                          // channels per lane while summing
     constexpr int ROWB = C * (int)sizeof(ST);          // bytes of one upstream-gradient row
-    constexpr int RS = C * 4 + 16;                     // LDS row stride: fp32 row + pad (banks)
+    // Rows are staged in the storage type.  (Staging bf16 rows as fp32 saves the unpack in the
+    // summation loop but doubles the LDS bytes, and this kernel is LDS-bound: ~80 % LDS busy.)
+    constexpr int SB = (int)sizeof(ST);                // bytes per staged element
+    constexpr int RS = C * SB + 16;                    // LDS row stride: row + pad (banks)
     constexpr int LPR = ROWB / 16;                     // lanes that fetch one row, 16 B each
     constexpr int RPP = 64 / LPR;                      // rows staged per pass
     constexpr int NPASS = R / RPP;                     // staging passes per round
@@ -331,40 +335,39 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         // Software pipeline over rounds of R records: everything global that round r+1 needs
         // (record ids, locations, weights, upstream-gradient rows) is issued at the top of
         // round r and consumed one iteration later.  Inactive lanes use record 0 (valid).
-        auto fetch_ids = [&](int rr) -> int {
-            return (rr + lane < item.z) ? rec[rr + lane] : 0;
+        struct Ids { int v[RPL]; };
+        auto fetch_ids = [&](int rr) -> Ids {
+            Ids r;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+                r.v[i] = (rr + i * 64 + lane < item.z) ? rec[rr + i * 64 + lane] : 0;
+            return r;
         };
-        int row_n = 0, mr_n = 0;                       // rows of the round being fetched
-        auto fetch_point = [&](int r, float2 &xy, float &as, float &al) {
-            const int q = r >> plan.lp_bits, lp = r & lp_mask;
-            row_n = (int)(((size_t)b * Lq + q) * H + h);
-            const size_t pid = (size_t)row_n * LP + lp;
-            xy = loc2[pid];
-            as = w_sp[pid];
-            al = INST ? w_lv[pid] : 0.f;
-            mr_n = INST ? (int)((((size_t)b * Lq + q) * P + lp % P) * H + h) : 0;
+        int row_n[RPL], mr_n[RPL];                     // rows of the round being fetched
+        auto fetch_point = [&](const Ids &r, float2 (&xy)[RPL], float (&as)[RPL],
+                               float (&al)[RPL]) {
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int q = r.v[i] >> plan.lp_bits, lp = r.v[i] & lp_mask;
+                row_n[i] = (int)(((size_t)b * Lq + q) * H + h);
+                const size_t pid = (size_t)row_n[i] * LP + lp;
+                xy[i] = loc2[pid];
+                as[i] = w_sp[pid];
+                al[i] = INST ? w_lv[pid] : 0.f;
+                mr_n[i] = INST ? (int)((((size_t)b * Lq + q) * P + lp % P) * H + h) : 0;
+            }
         };
         u32x4 grow[NPASS], mrow[INST ? NPASS : 1];     // rows in flight (registers)
-        // rows are staged as fp32 whatever the storage type: the conversion is paid once per
-        // record here instead of once per list entry in the summation loop
         auto stage_piece = [&](unsigned char *dst, u32x4 v) {
-            if constexpr (sizeof(ST) == 4) {
-                *reinterpret_cast<u32x4 *>(dst) = v;
-            } else {
-                u32x4 lo, hi;
-                lo.x = v.x << 16; lo.y = v.x & 0xffff0000u; lo.z = v.y << 16; lo.w = v.y & 0xffff0000u;
-                hi.x = v.z << 16; hi.y = v.z & 0xffff0000u; hi.z = v.w << 16; hi.w = v.w & 0xffff0000u;
-                *reinterpret_cast<u32x4 *>(dst) = lo;
-                *reinterpret_cast<u32x4 *>(dst + 16) = hi;
-            }
+            *reinterpret_cast<u32x4 *>(dst) = v;
         };
 #define BOXATTN_FETCH_ROWS()                                                                    \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
-        const int rj_ = __shfl(row_n, j_, 64);                                                  \
+        const int rj_ = __shfl(row_n[(ps * RPP) / 64], j_ % 64, 64);                            \
         grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj_ * C + piece_ * EPL); \
         if constexpr (INST) {                                                                   \
-            const int mj_ = __shfl(mr_n, j_, 64);                                               \
+            const int mj_ = __shfl(mr_n[(ps * RPP) / 64], j_ % 64, 64);                         \
             mrow[ps] =                                                                          \
                 *reinterpret_cast<const u32x4 *>(grad_mask + (size_t)mj_ * C + piece_ * EPL);   \
         }                                                                                       \
@@ -372,14 +375,16 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #define BOXATTN_STAGE_ROWS()                                                                    \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
-        stage_piece(&gstage[j_ * RS + piece_ * EPL * 4], grow[ps]);                             \
-        if constexpr (INST) stage_piece(&mstage[j_ * RS + piece_ * EPL * 4], mrow[ps]);         \
+        stage_piece(&gstage[j_ * RS + piece_ * 16], grow[ps]);                                  \
+        if constexpr (INST) stage_piece(&mstage[j_ * RS + piece_ * 16], mrow[ps]);              \
     }
-        float2 xy_c, xy_n = make_float2(0.f, 0.f);
-        float as_c, al_c, as_n = 0.f, al_n = 0.f;
+        float2 xy_c[RPL], xy_n[RPL];
+        float as_c[RPL], al_c[RPL], as_n[RPL], al_n[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { xy_n[i] = make_float2(0.f, 0.f); as_n[i] = al_n[i] = 0.f; }
         fetch_point(fetch_ids(item.y), xy_c, as_c, al_c);
         BOXATTN_FETCH_ROWS()
-        int rec_n = fetch_ids(item.y + R);
+        Ids rec_n = fetch_ids(item.y + R);
         BOXATTN_STAGE_ROWS()                           // round 0 staged directly
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
@@ -391,19 +396,27 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             }
             if (lane <= PB) pcnt[lane] = 0;
             wave_lds_sync();
-            // ---- phase 1: lane = record: geometry, rank inside the destination pixel lists.
-            //      Branch-free: corners outside this block go to dump slots.
-            const Sample<float> sm = locate<float>(xy_c.x, xy_c.y, lv.H, lv.W);
-            float wk[4] = {sm.hh * sm.hw, sm.hh * sm.lw, sm.lh * sm.hw, sm.lh * sm.lw};
-            int pixk[4], rank[4];
+            // ---- phase 1: lane = RPL records: geometry, rank inside the destination pixel
+            //      lists.  Branch-free: corners outside this block go to dump slots.
+            float wk[RPL][4];
+            int pixk[RPL][4], rank[RPL][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
-                const bool use = lane < n && sm.ok[k] && (yy >> 2) == by && (xx >> 3) == bx;
-                pixk[k] = use ? (yy - oy) * BW + (xx - ox) : PB;
+            for (int i = 0; i < RPL; ++i) {
+                const Sample<float> sm = locate<float>(xy_c[i].x, xy_c[i].y, lv.H, lv.W);
+                wk[i][0] = sm.hh * sm.hw; wk[i][1] = sm.hh * sm.lw;
+                wk[i][2] = sm.lh * sm.hw; wk[i][3] = sm.lh * sm.lw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
+                    const bool use = i * 64 + lane < n && sm.ok[k] && (yy >> 2) == by &&
+                                     (xx >> 3) == bx;
+                    pixk[i][k] = use ? (yy - oy) * BW + (xx - ox) : PB;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rank[k] = atomicAdd(&pcnt[pixk[k]], 1);
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rank[i][k] = atomicAdd(&pcnt[pixk[i][k]], 1);
             wave_lds_sync();
             {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips)
                 int ic = lane < PB ? pcnt[lane] : 0;
@@ -417,13 +430,16 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             }
             wave_lds_sync();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = pixk[k] < PB ? poff[pixk[k]] + rank[k] : 4 * R + UNR;
-                if constexpr (INST)
-                    ent[e] = make_float4(wk[k] * as_c, wk[k] * al_c, __int_as_float(lane), 0.f);
-                else
-                    ent[e] = make_float2(wk[k] * as_c, __int_as_float(lane));
-            }
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = pixk[i][k] < PB ? poff[pixk[i][k]] + rank[i][k] : 4 * R + UNR;
+                    const float slot = __int_as_float(i * 64 + lane);
+                    if constexpr (INST)
+                        ent[e] = make_float4(wk[i][k] * as_c[i], wk[i][k] * al_c[i], slot, 0.f);
+                    else
+                        ent[e] = make_float2(wk[i][k] * as_c[i], slot);
+                }
             wave_lds_sync();
             // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
             //      pixel's list, UNR entries per step (independent LDS reads in flight); the
@@ -456,12 +472,14 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 float v[UNR][CH];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const float4 *gp = reinterpret_cast<const float4 *>(
-                        &gstage[jj[u] * RS + half * (CH * 4)]);
+                    const ST *gp = reinterpret_cast<const ST *>(
+                        &gstage[jj[u] * RS + half * (CH * SB)]);
 #pragma unroll
-                    for (int c0 = 0; c0 < CH; c0 += 4) {
-                        const float4 t = gp[c0 / 4];
-                        v[u][c0] = t.x; v[u][c0 + 1] = t.y; v[u][c0 + 2] = t.z; v[u][c0 + 3] = t.w;
+                    for (int c0 = 0; c0 < CH; c0 += EPL) {
+                        float t[EPL];
+                        VecIO<ST, EPL>::ld(gp + c0, t);
+#pragma unroll
+                        for (int c = 0; c < EPL; ++c) v[u][c0 + c] = t[c];
                     }
                 }
 #pragma unroll
@@ -471,13 +489,14 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 if constexpr (INST) {
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        const float4 *mp = reinterpret_cast<const float4 *>(
-                            &mstage[jj[u] * RS + half * (CH * 4)]);
+                        const ST *mp = reinterpret_cast<const ST *>(
+                            &mstage[jj[u] * RS + half * (CH * SB)]);
 #pragma unroll
-                        for (int c0 = 0; c0 < CH; c0 += 4) {
-                            const float4 t = mp[c0 / 4];
-                            acc[c0] += wb[u] * t.x; acc[c0 + 1] += wb[u] * t.y;
-                            acc[c0 + 2] += wb[u] * t.z; acc[c0 + 3] += wb[u] * t.w;
+                        for (int c0 = 0; c0 < CH; c0 += EPL) {
+                            float t[EPL];
+                            VecIO<ST, EPL>::ld(mp + c0, t);
+#pragma unroll
+                            for (int c = 0; c < EPL; ++c) acc[c0 + c] += wb[u] * t[c];
                         }
                     }
                 }
@@ -485,7 +504,8 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             wave_lds_sync();
             if (more) {                                // stage round r+1 (rows have arrived)
                 BOXATTN_STAGE_ROWS()
-                xy_c = xy_n; as_c = as_n; al_c = al_n;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { xy_c[i] = xy_n[i]; as_c[i] = as_n[i]; al_c[i] = al_n[i]; }
             }
         }
 #undef BOXATTN_FETCH_ROWS

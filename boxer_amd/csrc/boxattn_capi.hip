@@ -466,7 +466,10 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     const int wg_per_slice = std::max(1, plan.item_cap);
     {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
-        hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST>), dim3(wg_per_slice, ns8),
+        // two records per lane and round pay off for bf16 box attention (fewer rounds: 141 ->
+        // 126 us); fp32 and the instance flavour run out of registers / LDS with it
+        constexpr int kRpl = (sizeof(ST) == 2 && !INST) ? 2 : 1;
+        hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
                            dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
                            d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
     }
