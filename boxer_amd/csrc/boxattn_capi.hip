@@ -299,9 +299,10 @@ struct SideStream {
     }
     hipStream_t main_, side_;
     PerDev *p_;
-    explicit SideStream(hipStream_t main) : main_(main), side_(main), p_(&slot())
+    // `worth` = the problem is big enough for the fork/join events to pay off
+    explicit SideStream(hipStream_t main, bool worth = true) : main_(main), side_(main), p_(&slot())
     {
-        if (!p_->s || g_variant == 4) return;                 // no helper: stay on the main stream
+        if (!p_->s || g_variant == 4 || !worth) return;       // no helper: stay on the main stream
         if (hipEventRecord(p_->fork, main_) == hipSuccess &&
             hipStreamWaitEvent(p_->s, p_->fork, 0) == hipSuccess)
             side_ = p_->s;
@@ -319,6 +320,7 @@ struct SideStream {
 
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
 constexpr int kChunk = 1024;          // records per work item
+constexpr size_t kSideStreamMinPoints = 1u << 20;   // below this the fork/join costs more than it hides
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -437,7 +439,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // library's helper stream, concurrently with the bin passes and the accumulate kernel, which
     // is latency-bound at ~13 waves per CU and leaves issue slots free.  Fork/join with events,
     // so the caller still sees one in-order stream (also valid under stream capture).
-    SideStream side(st);
+    SideStream side(st, d.n_qh() * d.L * d.P >= kSideStreamMinPoints);
     if (!plan_ready) launch_binning(loc, d, plan, w, ws, st);
     {
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
@@ -554,7 +556,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         ok = workspace_bytes >= w.total;
     }
     if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
-    SideStream side(st);
+    SideStream side(st, d.n_qh() * d.L * d.P >= kSideStreamMinPoints);
     launch_binning(loc, d, plan, w, (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     side.join();
