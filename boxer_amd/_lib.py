@@ -81,12 +81,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # BOXATTN_HIP_LIB: load another build of the same library (kernel tuning experiments,
+    # tools/build_variants.sh); it must export the same ABI.
+    path = os.environ.get("BOXATTN_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
             "%s is missing. Build it with `python setup.py build_ext --inplace` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). boxer_amd has no CPU "
-            "fallback by design." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "fallback by design." % path)
+    lib = ctypes.CDLL(path)
     lib.boxattn_abi_version.restype = _i
     lib.boxattn_build_info.restype = ctypes.c_char_p
     lib.boxattn_set_variant.argtypes = [_i]
@@ -105,7 +108,7 @@ def load():
     lib.boxattn_bwd_workspace_bytes.argtypes = [_i] * 8 + [_vp, _vp]
     lib.boxattn_bwd_workspace_bytes.restype = ctypes.c_size_t
     if lib.boxattn_abi_version() != ABI_VERSION:
-        raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
+        raise RuntimeError("ABI version mismatch in %s" % path)
     _lib = lib
     return lib
 

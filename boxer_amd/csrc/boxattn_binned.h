@@ -41,6 +41,9 @@ struct BinLevel {
     int blk0;             // first block id of this level inside a slice
 };
 
+#ifndef BOXATTN_TUNE_INTERLEAVE
+#define BOXATTN_TUNE_INTERLEAVE 1
+#endif
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // bin_scan_a_kernel: sub-ranges of workgroups
 constexpr int kMaxBinLevels = 8;   // levels the binned backward plans for (BoxeR uses 2-5)
 
@@ -94,9 +97,21 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc,
     int *hist = sh_bins;
     const int s = blockIdx.y, b = s / H, h = s % H;
     const int LP = plan.L * P;
-    const int q0 = blockIdx.x * q_per_wg;
-    const int q1 = min(q0 + q_per_wg, Lq);
-    const int n_pts = (q1 - q0) * LP;
+    // Workgroup w takes the queries w, w + n_wg, w + 2 n_wg, ...: every workgroup's records are
+    // then a uniform sample of the map, and so is any run of consecutive records of a bin.  The
+    // accumulate kernel works through a bin 64-128 records at a time with one lane per
+    // destination pixel; with contiguous query ranges a round's records came from neighbouring
+    // queries and piled up on a few pixels (longest per-pixel list 3.3x the mean; interleaved
+    // 2.1x, profiles/r02_* notes).
+#if BOXATTN_TUNE_INTERLEAVE
+    const int q0 = blockIdx.x, qstep = gridDim.x;
+    const int n_q = q0 < Lq ? (Lq - q0 + qstep - 1) / qstep : 0;
+    (void)q_per_wg;
+#else
+    const int q0 = blockIdx.x * q_per_wg, qstep = 1;
+    const int n_q = max(0, min(q0 + q_per_wg, Lq) - q0);
+#endif
+    const int n_pts = n_q * LP;
     int *mypart = part + ((size_t)s * gridDim.x + blockIdx.x) * plan.nblk;
     __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane below (no select chains)
     if (threadIdx.x == 0) {
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc,
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     constexpr int U = 4;                          // points per thread per step (loads in flight)
     const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
-    const size_t qstride = (size_t)H * LP;                          // points between queries
+    const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
     const float rcp_lp = 1.0f / (float)LP;
     int *rec = records + (size_t)s * plan.rec_cap;
     for (int i0 = threadIdx.x; i0 < n_pts; i0 += blockDim.x * U) {
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc,
             for (int j = 0; j < 4; ++j) {
                 if (blk[j] >= 0) {
                     const int slot = atomicAdd(&hist[blk[j]], 1);      // LDS
-                    if (FILL) rec[slot] = ((q0 + ql[u]) << plan.lp_bits) | lp[u];
+                    if (FILL) rec[slot] = ((q0 + ql[u] * qstep) << plan.lp_bits) | lp[u];
                 }
             }
         }
@@ -281,6 +296,19 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     constexpr int UNR = 2;                             // list entries handled per step
     typedef typename std::conditional<INST, float4, float2>::type Entry;   // {w*a_s[, w*a_l], j}
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector: stays in VGPRs
+    constexpr int NQ = CH * SB / 16;                   // 16-byte pieces of a lane's half row
+    // channels (2i, 2i+1) of a staged half row as two floats
+    auto staged_pair = [](const u32x4 (&rw)[NQ], int i) -> f32x2 {
+        f32x2 r;
+        if constexpr (SB == 4) {
+            r.x = __uint_as_float(rw[(2 * i) / 4][(2 * i) % 4]);
+            r.y = __uint_as_float(rw[(2 * i + 1) / 4][(2 * i + 1) % 4]);
+        } else {
+            const unsigned wd = rw[i / 4][i % 4];
+            r.x = __uint_as_float(wd << 16); r.y = __uint_as_float(wd & 0xffff0000u);
+        }
+        return r;
+    };
     // row R of the stages is all zeros: the target of padded (unused) list entries
     __shared__ __attribute__((aligned(16))) unsigned char gstage[(R + 1) * RS];
     __shared__ __attribute__((aligned(16))) unsigned char mstage[INST ? (R + 1) * RS : 16];
@@ -328,9 +356,9 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         const int oy = by * BH, ox = bx * BW;
         const int *rec = records + (size_t)s * plan.rec_cap +
                          offsets[(size_t)s * (plan.nblk + 1) + blk];
-        float acc[CH];
+        f32x2 acc[CH / 2];                           // channel pairs (2i, 2i+1) of this half
 #pragma unroll
-        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+        for (int i = 0; i < CH / 2; ++i) acc[i] = f32x2{0.f, 0.f};
 
         // Software pipeline over rounds of R records: everything global that round r+1 needs
         // (record ids, locations, weights, upstream-gradient rows) is issued at the top of
@@ -469,35 +497,36 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                         jj[u] = live ? __float_as_int(en[u].y) : R;
                     }
                 }
-                float v[UNR][CH];
+                // rows as raw words, then packed math: one v_pk_fma_f32 per channel pair
+                u32x4 rw[UNR][NQ];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const ST *gp = reinterpret_cast<const ST *>(
+                    const u32x4 *gp = reinterpret_cast<const u32x4 *>(
                         &gstage[jj[u] * RS + half * (CH * SB)]);
 #pragma unroll
-                    for (int c0 = 0; c0 < CH; c0 += EPL) {
-                        float t[EPL];
-                        VecIO<ST, EPL>::ld(gp + c0, t);
-#pragma unroll
-                        for (int c = 0; c < EPL; ++c) v[u][c0 + c] = t[c];
-                    }
+                    for (int q = 0; q < NQ; ++q) rw[u][q] = gp[q];
                 }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
+                for (int u = 0; u < UNR; ++u) {
+                    const f32x2 w2 = {wa[u], wa[u]};
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) acc[c] += wa[u] * v[u][c];
+                    for (int i = 0; i < CH / 2; ++i)
+                        acc[i] = __builtin_elementwise_fma(w2, staged_pair(rw[u], i), acc[i]);
+                }
                 if constexpr (INST) {
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        const ST *mp = reinterpret_cast<const ST *>(
+                        const u32x4 *mp = reinterpret_cast<const u32x4 *>(
                             &mstage[jj[u] * RS + half * (CH * SB)]);
 #pragma unroll
-                        for (int c0 = 0; c0 < CH; c0 += EPL) {
-                            float t[EPL];
-                            VecIO<ST, EPL>::ld(mp + c0, t);
+                        for (int q = 0; q < NQ; ++q) rw[u][q] = mp[q];
+                    }
 #pragma unroll
-                            for (int c = 0; c < EPL; ++c) acc[c0 + c] += wb[u] * t[c];
-                        }
+                    for (int u = 0; u < UNR; ++u) {
+                        const f32x2 w2 = {wb[u], wb[u]};
+#pragma unroll
+                        for (int i = 0; i < CH / 2; ++i)
+                            acc[i] = __builtin_elementwise_fma(w2, staged_pair(rw[u], i), acc[i]);
                     }
                 }
             }
@@ -524,7 +553,9 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 for (int c = 0; c < CH; c += EPL) {
                     float t[EPL];
 #pragma unroll
-                    for (int i = 0; i < EPL; ++i) t[i] = acc[c + i];
+                    for (int i = 0; i < EPL; i += 2) {
+                        t[i] = acc[(c + i) / 2].x; t[i + 1] = acc[(c + i) / 2].y;
+                    }
                     VecIO<ST, EPL>::st(dst + c, t);
                 }
             }
@@ -534,7 +565,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #pragma unroll
             for (int c = 0; c < CH; c += 4)
                 *reinterpret_cast<float4 *>(dst + c) =
-                    make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+                    make_float4(acc[c / 2].x, acc[c / 2].y, acc[c / 2 + 1].x, acc[c / 2 + 1].y);
         }
     }
 }

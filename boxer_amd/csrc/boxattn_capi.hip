@@ -59,6 +59,47 @@ bool fast_ok(const Dims &d, const void *value, const void *loc, const void *a, c
            aligned(c, va);
 }
 
+// Lanes per (query, head) pair and channels per lane of the gather kernels (boxattn_gather2.h):
+// 8 channels per lane when C allows and the rows can be fetched 16 bytes at a time.
+#ifndef BOXATTN_TUNE_VEC_F32
+#define BOXATTN_TUNE_VEC_F32 4      // measured: 128-byte fp32 rows gain nothing from 8 channels per lane
+#endif
+#ifndef BOXATTN_TUNE_VEC_BF16
+#define BOXATTN_TUNE_VEC_BF16 8
+#endif
+#ifndef BOXATTN_TUNE_U8_F32
+#define BOXATTN_TUNE_U8_F32 2
+#endif
+#ifndef BOXATTN_TUNE_U8_BF16
+#define BOXATTN_TUNE_U8_BF16 4
+#endif
+#ifndef BOXATTN_TUNE_U4_F32
+#define BOXATTN_TUNE_U4_F32 4      // 0: all G points of a tile
+#endif
+#ifndef BOXATTN_TUNE_U4_BF16
+#define BOXATTN_TUNE_U4_BF16 4
+#endif
+struct GatherCfg { int G, VEC; };
+template <typename ST> inline GatherCfg gather_cfg(const Dims &d, bool rows_16b_aligned)
+{
+    constexpr int want = sizeof(ST) == 2 ? BOXATTN_TUNE_VEC_BF16 : BOXATTN_TUNE_VEC_F32;
+    if (want == 8 && rows_16b_aligned && (d.C == 32 || d.C == 64)) return {d.C / 8, 8};
+    return {fast_group(d), 4};
+}
+// points of a pair in flight per lane (loads issued before the first use)
+template <typename ST, int G, int VEC> struct GatherUnroll {
+    static constexpr int u8 = sizeof(ST) == 2 ? BOXATTN_TUNE_U8_BF16 : BOXATTN_TUNE_U8_F32;
+    static constexpr int u4 = sizeof(ST) == 2 ? BOXATTN_TUNE_U4_BF16 : BOXATTN_TUNE_U4_F32;
+    static constexpr int want = VEC == 8 ? u8 : u4;
+    static constexpr int value = (want <= 0 || want > G) ? G : want;
+};
+#define BOXATTN_GATHER_DISPATCH(cfg, X)                                                       \
+    do {                                                                                      \
+        if ((cfg).VEC == 8) {                                                                 \
+            if ((cfg).G == 4) { X(4, 8) } else { X(8, 8) }                                    \
+        } else if ((cfg).G == 4) { X(4, 4) } else if ((cfg).G == 8) { X(8, 4) } else { X(16, 4) } \
+    } while (0)
+
 // How many workgroups should share the point tiles of a (query, head) pair: aim at ~4096
 // workgroups when the query dimension alone gives fewer than 1024.
 inline int point_split(int blocks, int tiles)
@@ -143,11 +184,15 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     if constexpr (!std::is_same<ST, double>::value) {
         if (fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out,
                         out)) {
-            const int G = fast_group(d);
-            const int pairs = kWave / G;
-            const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
             const size_t vbytes = d.n_value() * sizeof(ST);
             const bool gen2 = g_variant != 2 && vbytes < kOobOffset;   // buffer-load kernels
+            const GatherCfg cfg =
+                gen2 ? gather_cfg<ST>(d, aligned(value, 16) && aligned(out, 16) &&
+                                         (!INST || aligned(mask, 16)))
+                     : GatherCfg{fast_group(d), 4};
+            const int G = cfg.G;
+            const int pairs = kWave / G;
+            const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
             // instance attention with few queries and many points: split the points of a pair
             // over several workgroups (fp32 only: partial outs are combined with atomics)
             int fsplit = 1;
@@ -158,24 +203,27 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                 if (e != hipSuccess) return (int)e;
             }
             ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+            if (gen2) {
+#define BOXATTN_FWD2(GG, VV)                                                                  \
+    hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
+                       dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
+                       w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh, (unsigned)vbytes);
+                BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2);
+#undef BOXATTN_FWD2
+            } else {
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
-        if (gen2)                                                                             \
-            hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, (sizeof(ST) == 2 && GG >= 4) ? 4 : GG>), \
-                               dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, \
-                               w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh,         \
-                               (unsigned)vbytes);                                             \
-        else                                                                                  \
-            hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, \
-                               st, value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, \
-                               d.P, out, mask, n_qh);                                         \
+        hipLaunchKernelGGL((fwd_fast_kernel<ST, 4, GG, INST>), dim3(blocks), dim3(256), 0, st, \
+                           value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out, \
+                           mask, n_qh);                                                       \
         break;
-            switch (G) {
-                BOXATTN_FWD_CASE(4)
-                BOXATTN_FWD_CASE(8)
-                BOXATTN_FWD_CASE(16)
-            }
+                switch (G) {
+                    BOXATTN_FWD_CASE(4)
+                    BOXATTN_FWD_CASE(8)
+                    BOXATTN_FWD_CASE(16)
+                }
 #undef BOXATTN_FWD_CASE
+            }
             return finish();
         }
         if (g_variant == 2) return (int)hipErrorInvalidValue;
@@ -445,19 +493,26 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
         const size_t n_qh = d.n_qh();
-        const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
         const size_t vbytes = d.n_value() * sizeof(ST);
-        if (vbytes < kOobOffset)
-            hipLaunchKernelGGL((pointgrad2_kernel<ST, G, INST>),
-                               dim3(blocks, point_split(blocks, (d.L * d.P + G - 1) / G)),
-                               dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out,
-                               grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,
-                               n_qh, (unsigned)vbytes);
-        else
+        if (vbytes < kOobOffset) {
+            const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
+                                                    (!INST || aligned(grad_mask, 16)));
+            const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / cfg.G) * 4);
+            const int split = point_split(blocks, (d.L * d.P + cfg.G - 1) / cfg.G);
+#define BOXATTN_PG2(GG, VV)                                                                   \
+    hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
+                       dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
+                       w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
+                       grad_lv, n_qh, (unsigned)vbytes);
+            BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
+#undef BOXATTN_PG2
+        } else {
+            const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
             hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
                                0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
                                d.S, d.H, d.L, d.Lq, d.P, (float *)nullptr, grad_loc, grad_sp, grad_lv,
                                n_qh);
+        }
     }
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
     // real count lives on the device, surplus workgroups exit at once).  ~13 fit per CU (LDS),

@@ -44,6 +44,14 @@ template <> struct Storage<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 };
 
+// Two fp32 -> packed bf16 pair, round-to-nearest-even, one v_cvt_pk_bf16_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 // Vector access of VEC consecutive channels (VEC*sizeof(ST) is 8 or 16 bytes, aligned).
 template <typename ST, int VEC> struct VecIO;
 template <> struct VecIO<float, 4> {
@@ -63,8 +71,8 @@ template <> struct VecIO<bf16_t, 4> {
     }
     static __device__ __forceinline__ void st(bf16_t *p, const float (&v)[4]) {
         uint2 t;
-        t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        t.x = pack_bf16x2(v[0], v[1]);
+        t.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2 *>(p) = t;
     }
 };
@@ -78,10 +86,10 @@ template <> struct VecIO<bf16_t, 8> {
     }
     static __device__ __forceinline__ void st(bf16_t *p, const float (&v)[8]) {
         uint4 t;
-        t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-        t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        t.x = pack_bf16x2(v[0], v[1]);
+        t.y = pack_bf16x2(v[2], v[3]);
+        t.z = pack_bf16x2(v[4], v[5]);
+        t.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4 *>(p) = t;
     }
 };

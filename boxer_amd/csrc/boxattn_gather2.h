@@ -1,21 +1,25 @@
 // Second-generation gather kernels (forward, and the point-gradient half of the backward).
 //
-// Measured on the first fast kernels (profiles/r01_step2_*): ~134 (fwd) / ~190 (bwd) VALU
-// instructions per sample point and lane, half of them the bilinear geometry that all G lanes
-// of a (query, head) group recomputed redundantly, plus 64-bit address arithmetic and
-// select-to-zero of out-of-map corners.  Here:
+// Both kernels are bound by VALU issue (PMC: 65-80 % of the VALU slots busy, HBM < 1.5 TB/s),
+// so the design minimises wave instructions per sample point:
 //
 //   step A  lane (pair j, slot t) does the geometry of ONE sample point of pair j -- G points
 //           per pair at a time -- and leaves {4 byte offsets, 4 weights, ...} in a wave-private
 //           LDS tile (no workgroup barrier: producer and consumers are the same wavefront);
-//   step B  lane (pair j, channel chunk m) walks the G points of its pair: one 32-byte LDS
-//           broadcast read per point, four BUFFER loads (32-bit offset, the hardware range
-//           check returns 0 for the out-of-map marker, so no address select and no
-//           select-to-zero), 16 FMAs.
+//   step B  lane (pair j, channel chunk m) walks the G points of its pair: one LDS broadcast
+//           read per point, four BUFFER loads of VEC channels (32-bit offset, the hardware
+//           range check returns 0 for the out-of-map marker, so no address select and no
+//           select-to-zero), then packed math: v_pk_fma_f32 on channel pairs (two FMAs per
+//           lane and instruction).
 //
-// The backward flavour accumulates S_k = sum_c g_c * v_k,c for the four corners (4 FMAs per
-// channel instead of 16 ops), reduces the four sums over the G lanes with DPP, hands them to
-// lane (j, t) and lets that lane finish grad_loc / grad_weight from its own step-A registers:
+// VEC = 8 channels per lane (16-byte loads for bf16, 2 x 16 bytes for fp32) whenever C allows:
+// G = C / VEC lanes per (query, head) pair, so the per-point overhead (tile read, offset adds)
+// is spread over twice the channels of the VEC = 4 layout.
+//
+// The backward flavour accumulates S_k = sum_c g_c * v_k,c for the four corners (bf16: one
+// v_dot2c_f32_bf16 per channel PAIR straight on the packed words, no unpack; fp32: v_pk_fma),
+// reduces the four sums over the G lanes with DPP, hands them to lane (j, t) and lets that
+// lane finish grad_loc / grad_weight from its own step-A registers:
 //   grad_w   = sum_k w_k S_k
 //   grad_x   = W_l * a * (hh (S2 - S1) + lh (S4 - S3))
 //   grad_y   = H_l * a * (hw (S3 - S1) + lw (S4 - S2))
@@ -31,64 +35,193 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOobOffset = 0x80000000u;     // >= any valid byte offset (tensor < 2 GiB)
 
-template <typename ST> struct BufLd;
-template <> struct BufLd<float> {                 // 4 channels = 16 bytes
-    static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[4]) {
-        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
-        v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
-    }
+// Tuning switches (tools/build_variants.sh builds the alternatives side by side).
+#ifndef BOXATTN_TUNE_SCHED
+#define BOXATTN_TUNE_SCHED 1      // all row loads of a step are issued before the first FMA
+#endif
+#ifndef BOXATTN_TUNE_PREFETCH
+#define BOXATTN_TUNE_PREFETCH 1   // locations / weights of tile t+1 are requested during tile t
+#endif
+constexpr bool kGatherSched = BOXATTN_TUNE_SCHED != 0;
+constexpr bool kGatherPrefetch = BOXATTN_TUNE_PREFETCH != 0;
+__device__ __forceinline__ void loads_issued()
+{
+    // keep the compiler from sinking loads below the math to save registers: the point of the
+    // step is to have them all in flight at once
+    if constexpr (kGatherSched) __builtin_amdgcn_sched_barrier(0);
+}
+
+// The VEC channels a lane owns, as raw 32-bit words (fp32: VEC words, bf16: VEC / 2 words).
+// They are fetched in 16-byte pieces (8 bytes for bf16 x 4).  A lane with two pieces (fp32,
+// VEC = 8) owns channels [4 slot, 4 slot + 4) and [4 G + 4 slot, ...): piece i of the G lanes
+// of a pair is then one contiguous 16 G-byte run, i.e. every load instruction touches whole
+// 64-byte segments (two pieces side by side per lane would leave 16-byte holes in each
+// instruction's footprint and cost twice the L1 tag lookups).
+template <typename ST, int VEC> struct Row {
+    static constexpr int NW = VEC * (int)sizeof(ST) / 4;
+    static constexpr int NP = NW > 4 ? NW / 4 : 1;               // pieces per lane
+    static constexpr int kLaneBytes = VEC * (int)sizeof(ST) / NP;  // bytes of one piece
+    unsigned w[NW];
 };
-template <> struct BufLd<bf16_t> {                // 4 channels = 8 bytes
-    static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[4]) {
-        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    }
+// byte distance between the pieces of a lane
+template <typename ST, int VEC, int G> struct RowGeom {
+    static constexpr int kPieceStride = Row<ST, VEC>::kLaneBytes * G;
 };
 
-struct GeoBox { unsigned off[4]; float w[4]; };                     // 32 bytes
-struct GeoInst { unsigned off[4]; float w[4]; float as, al, pad0, pad1; };   // 48 bytes
+template <typename ST, int VEC, int PSB>
+__device__ __forceinline__ void row_load(__amdgpu_buffer_rsrc_t r, unsigned off, Row<ST, VEC> &v)
+{
+    constexpr int NW = Row<ST, VEC>::NW;
+    if constexpr (NW == 2) {
+        const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        v.w[0] = t.x; v.w[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) {
+            const u32x4_t t =
+                __builtin_amdgcn_raw_buffer_load_b128(r, off + (unsigned)(PSB * i), 0, 0);
+            v.w[4 * i] = t.x; v.w[4 * i + 1] = t.y; v.w[4 * i + 2] = t.z; v.w[4 * i + 3] = t.w;
+        }
+    }
+}
+
+template <typename ST, int VEC, int PSB>
+__device__ __forceinline__ void row_load(const ST *p, Row<ST, VEC> &v)
+{
+    constexpr int NW = Row<ST, VEC>::NW;
+    if constexpr (NW == 2) {
+        const u32x2_t t = *reinterpret_cast<const u32x2_t *>(p);
+        v.w[0] = t.x; v.w[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) {
+            const u32x4_t t = *reinterpret_cast<const u32x4_t *>(
+                reinterpret_cast<const char *>(p) + PSB * i);
+            v.w[4 * i] = t.x; v.w[4 * i + 1] = t.y; v.w[4 * i + 2] = t.z; v.w[4 * i + 3] = t.w;
+        }
+    }
+}
+
+// channels (2i, 2i+1) of a row as two floats
+template <typename ST, int VEC>
+__device__ __forceinline__ f32x2 row_pair(const Row<ST, VEC> &v, int i)
+{
+    f32x2 r;
+    if constexpr (sizeof(ST) == 4) {
+        r.x = __uint_as_float(v.w[2 * i]); r.y = __uint_as_float(v.w[2 * i + 1]);
+    } else {
+        r.x = __uint_as_float(v.w[i] << 16); r.y = __uint_as_float(v.w[i] & 0xffff0000u);
+    }
+    return r;
+}
+
+// acc (VEC / 2 channel pairs) += w * row
+template <typename ST, int VEC>
+__device__ __forceinline__ void row_axpy(f32x2 (&acc)[VEC / 2], float w, const Row<ST, VEC> &v)
+{
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i)
+        acc[i] = __builtin_elementwise_fma(w2, row_pair<ST, VEC>(v, i), acc[i]);
+}
+
+// sum_c g_c * v_c over the lane's VEC channels
+template <typename ST, int VEC>
+__device__ __forceinline__ float row_dot(const Row<ST, VEC> &g, const Row<ST, VEC> &v)
+{
+    if constexpr (sizeof(ST) == 4) {
+        f32x2 a = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < VEC / 2; ++i)
+            a = __builtin_elementwise_fma(row_pair<ST, VEC>(g, i), row_pair<ST, VEC>(v, i), a);
+        return a.x + a.y;
+    } else {
+        float a = 0.f;                               // bf16 x bf16 products are exact in fp32
+#pragma unroll
+        for (int i = 0; i < VEC / 2; ++i)
+            a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, g.w[i]),
+                                                __builtin_bit_cast(bf16x2_t, v.w[i]), a, false);
+        return a;
+    }
+}
+
+template <typename ST, int VEC, int PSB>
+__device__ __forceinline__ void row_store(ST *p, const f32x2 (&acc)[VEC / 2])
+{
+    if constexpr (sizeof(ST) == 4) {
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i)
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(p) + PSB * i) =
+                make_float4(acc[2 * i].x, acc[2 * i].y, acc[2 * i + 1].x, acc[2 * i + 1].y);
+    } else if constexpr (VEC == 4) {
+        u32x2_t t;
+        t.x = pack_bf16x2(acc[0].x, acc[0].y); t.y = pack_bf16x2(acc[1].x, acc[1].y);
+        *reinterpret_cast<u32x2_t *>(p) = t;
+    } else {
+        u32x4_t t;
+        t.x = pack_bf16x2(acc[0].x, acc[0].y); t.y = pack_bf16x2(acc[1].x, acc[1].y);
+        t.z = pack_bf16x2(acc[2].x, acc[2].y); t.w = pack_bf16x2(acc[3].x, acc[3].y);
+        *reinterpret_cast<u32x4_t *>(p) = t;
+    }
+}
+
+// The wave-private geometry tile: per point NH 16-byte pieces {4 offsets}{4 weights}[{as, al}],
+// one 16-byte pad per G-lane group so that the groups' broadcast reads start on different banks.
+template <int G, int NH> struct GeoTile {
+    static constexpr int kGroupStride = G * NH + 1;
+    static constexpr int kSize = (kWave / G) * kGroupStride;
+    static __device__ __forceinline__ int base(int lane) { return (lane / G) * kGroupStride; }
+};
 
 // Step A for one point: byte offsets of the four corners (row of head h, channel 0) or the
-// out-of-map marker, and the bilinear weights.
+// out-of-map marker.
 template <typename ST>
-__device__ __forceinline__ void corner_offsets(const Sample<float> &s, unsigned row0, int H, int h,
-                                               int C, unsigned (&off)[4])
+__device__ __forceinline__ u32x4_t corner_offsets(const Sample<float> &s, unsigned row0, int H, int h,
+                                                  int C, bool have)
 {
+    unsigned off[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        off[k] = s.ok[k] ? ((row0 + (unsigned)s.pix[k]) * H + h) * (unsigned)(C * sizeof(ST))
-                         : kOobOffset;
+        off[k] = (have && s.ok[k])
+                     ? ((row0 + (unsigned)s.pix[k]) * H + h) * (unsigned)(C * sizeof(ST))
+                     : kOobOffset;
+    u32x4_t r = {off[0], off[1], off[2], off[3]};
+    return r;
+}
+
+__device__ __forceinline__ u32x4_t as_u32x4(float a, float b, float c, float d)
+{
+    u32x4_t r = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <typename ST, int G, bool INST, int U = G>
+template <typename ST, int G, bool INST, int U, int VEC>
 __global__ __launch_bounds__(256) void fwd2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, size_t n_qh, unsigned value_bytes)
 {
-    constexpr int VEC = 4, C = VEC * G, PAIRS = kWave / G;
-    typedef typename std::conditional<INST, GeoInst, GeoBox>::type Geo;
+    constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
+    typedef GeoTile<G, NH> Tile;
+    typedef Row<ST, VEC> RowT;
+    constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;    // bytes between a lane's pieces
+    constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);   // channels of one piece
     __shared__ LevelTable lv;
-    // one pad slot per G-lane group: the groups' broadcast reads then fall on different banks
-    __shared__ __attribute__((aligned(16))) Geo geo_all[4][kWave + kWave / G];
+    __shared__ u32x4_t geo_all[4][Tile::kSize];
     load_levels(lv, shapes, lsi, L);
 
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    Geo *geo = geo_all[wv];
+    u32x4_t *geo = geo_all[wv] + Tile::base(lane);   // this group's part of the tile
     const size_t wave = (size_t)bid * (blockDim.x / kWave) + wv;
     size_t qh = wave * PAIRS + lane / G;
     const bool active = qh < n_qh;
     if (!active) qh = n_qh - 1;
     const int slot = lane % G;                      // step A: point slot; step B: channel chunk
-    const int grp0 = (lane & ~(G - 1)) + lane / G;  // padded tile index of the group's slot 0
-    const int myslot = grp0 + lane % G;
     const int h = (int)(qh % H);
     const size_t bq = qh / H;
     const unsigned b = (unsigned)(bq / Lq);
@@ -97,120 +230,161 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const size_t pt0 = qh * LP;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(value), 0, value_bytes, 0x00020000);
-    const unsigned lane_off = (unsigned)(slot * VEC * sizeof(ST));
+    const unsigned lane_off = (unsigned)(slot * RowT::kLaneBytes);
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    // (n + 0.5) * rcp_p truncates to n / P for every n < L * P <= 2^16: the product is at least
+    // 0.5 / P away from an integer, far more than the rounding error of the two operations
+    const float rcp_p = 1.0f / (float)P;
 
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 acc[VEC / 2];
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) acc[i] = f32x2{0.f, 0.f};
 
     if constexpr (!INST) {
+        float2 xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
+        float a_n = w_sp[pt0 + min(slot, LP - 1)];
         for (int t0 = 0; t0 < LP; t0 += G) {
             {   // ---- step A
                 const int lp = t0 + slot;
-                Geo g;
-                if (lp < LP) {
-                    const int l = lp / P;
-                    const float2 xy = loc2[pt0 + lp];
-                    const float a = w_sp[pt0 + lp];
-                    const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
-                    corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, g.off);
-                    g.w[0] = s.hh * s.hw * a; g.w[1] = s.hh * s.lw * a;
-                    g.w[2] = s.lh * s.hw * a; g.w[3] = s.lh * s.lw * a;
+                const bool have = lp < LP;
+                const int lq = have ? lp : LP - 1;
+                const int l = (int)(((float)lq + 0.5f) * rcp_p);   // lq / P (exact, see rcp_p)
+                float2 xy;
+                float a;
+                if constexpr (kGatherPrefetch) {
+                    xy = xy_n;
+                    a = have ? a_n : 0.f;
+                    const int nq = min(lp + G, LP - 1);           // same point again past the end
+                    xy_n = loc2[pt0 + nq];
+                    a_n = w_sp[pt0 + nq];
                 } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { g.off[k] = kOobOffset; g.w[k] = 0.f; }
+                    xy = loc2[pt0 + lq];
+                    a = have ? w_sp[pt0 + lq] : 0.f;
                 }
+                const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
+                const u32x4_t off =
+                    corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
+                const u32x4_t wt = as_u32x4(s.hh * s.hw * a, s.hh * s.lw * a, s.lh * s.hw * a,
+                                            s.lh * s.lw * a);
                 wave_lds_sync();                   // previous tile fully consumed
-                geo[myslot] = g;
+                geo[slot * NH] = off;
+                geo[slot * NH + 1] = wt;
                 wave_lds_sync();
             }
             // ---- step B (U points' loads in flight at a time)
 #pragma unroll 1
             for (int tb = 0; tb < G; tb += U) {
+                u32x4_t off[U], wt[U];
+                RowT v[U][4];
 #pragma unroll
-                for (int t = tb; t < tb + U; ++t) {
-                    const Geo g = geo[grp0 + t];
-                    float v[4][VEC];
+                for (int u = 0; u < U; ++u) {
+                    off[u] = geo[(tb + u) * NH];
+                    wt[u] = geo[(tb + u) * NH + 1];
+                    row_load<ST, VEC, PSB>(rs, off[u].x + lane_off, v[u][0]);
+                    row_load<ST, VEC, PSB>(rs, off[u].y + lane_off, v[u][1]);
+                    row_load<ST, VEC, PSB>(rs, off[u].z + lane_off, v[u][2]);
+                    row_load<ST, VEC, PSB>(rs, off[u].w + lane_off, v[u][3]);
+                }
+                loads_issued();
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) BufLd<ST>::ld(rs, g.off[k] + lane_off, v[k]);
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c)
-                        acc[c] += g.w[0] * v[0][c] + g.w[1] * v[1][c] + g.w[2] * v[2][c] +
-                                  g.w[3] * v[3][c];
+                for (int u = 0; u < U; ++u) {
+                    row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].x), v[u][0]);
+                    row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].y), v[u][1]);
+                    row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].z), v[u][2]);
+                    row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].w), v[u][3]);
                 }
             }
         }
     } else {
-        ST *mk = mask + bq * P * HC + (size_t)h * C + slot * VEC;
+        ST *mk = mask + bq * P * HC + (size_t)h * C + slot * LCH;
         // few queries x many points (decoder, 14x14 grids): gridDim.y workgroups share the
         // point tiles of a (query, head) pair; out is then accumulated with atomics
         const int tiles = (P + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
         const int p_begin = (int)blockIdx.y * tps * G, p_end = min(P, p_begin + tps * G);
         for (int p0 = p_begin; p0 < p_end; p0 += G) {
-            float macc[G][VEC];
+            f32x2 macc[G][VEC / 2];
 #pragma unroll
             for (int t = 0; t < G; ++t)
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) macc[t][c] = 0.f;
+                for (int i = 0; i < VEC / 2; ++i) macc[t][i] = f32x2{0.f, 0.f};
             for (int l = 0; l < L; ++l) {
                 {   // ---- step A: points (l, p0 .. p0+G-1)
                     const int p = p0 + slot;
-                    Geo g;
-                    if (p < P) {
-                        const size_t i = pt0 + (size_t)l * P + p;
-                        const float2 xy = loc2[i];
-                        g.as = w_sp[i];
-                        g.al = w_lv[i];
-                        const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
-                        corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C,
-                                           g.off);
-                        g.w[0] = s.hh * s.hw; g.w[1] = s.hh * s.lw;
-                        g.w[2] = s.lh * s.hw; g.w[3] = s.lh * s.lw;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { g.off[k] = kOobOffset; g.w[k] = 0.f; }
-                        g.as = 0.f; g.al = 0.f;
-                    }
-                    g.pad0 = 0.f; g.pad1 = 0.f;
+                    const bool have = p < P;
+                    const size_t i = pt0 + (size_t)l * P + (have ? p : P - 1);
+                    const float2 xy = loc2[i];
+                    const float as = have ? w_sp[i] : 0.f;
+                    const float al = have ? w_lv[i] : 0.f;
+                    const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
+                    const u32x4_t off = corner_offsets<ST>(
+                        s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
+                    const u32x4_t wt =
+                        as_u32x4(s.hh * s.hw, s.hh * s.lw, s.lh * s.hw, s.lh * s.lw);
                     wave_lds_sync();
-                    geo[myslot] = g;
+                    geo[slot * NH] = off;
+                    geo[slot * NH + 1] = wt;
+                    geo[slot * NH + 2] = as_u32x4(as, al, 0.f, 0.f);
                     wave_lds_sync();
                 }
 #pragma unroll
-                for (int t = 0; t < G; ++t) {
-                    const Geo g = geo[grp0 + t];
-                    float v[4][VEC];
+                for (int tb = 0; tb < G; tb += U) {
+                    u32x4_t off[U], wt[U], aa[U];
+                    RowT v[U][4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) BufLd<ST>::ld(rs, g.off[k] + lane_off, v[k]);
+                    for (int u = 0; u < U; ++u) {
+                        off[u] = geo[(tb + u) * NH];
+                        wt[u] = geo[(tb + u) * NH + 1];
+                        aa[u] = geo[(tb + u) * NH + 2];
+                        row_load<ST, VEC, PSB>(rs, off[u].x + lane_off, v[u][0]);
+                        row_load<ST, VEC, PSB>(rs, off[u].y + lane_off, v[u][1]);
+                        row_load<ST, VEC, PSB>(rs, off[u].z + lane_off, v[u][2]);
+                        row_load<ST, VEC, PSB>(rs, off[u].w + lane_off, v[u][3]);
+                    }
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-                        const float val = g.w[0] * v[0][c] + g.w[1] * v[1][c] + g.w[2] * v[2][c] +
-                                          g.w[3] * v[3][c];
-                        acc[c] += val * g.as;
-                        macc[t][c] += val * g.al;
+                    for (int u = 0; u < U; ++u) {
+                        f32x2 val[VEC / 2];
+#pragma unroll
+                        for (int i = 0; i < VEC / 2; ++i) val[i] = f32x2{0.f, 0.f};
+                        row_axpy<ST, VEC>(val, __uint_as_float(wt[u].x), v[u][0]);
+                        row_axpy<ST, VEC>(val, __uint_as_float(wt[u].y), v[u][1]);
+                        row_axpy<ST, VEC>(val, __uint_as_float(wt[u].z), v[u][2]);
+                        row_axpy<ST, VEC>(val, __uint_as_float(wt[u].w), v[u][3]);
+                        const float as = __uint_as_float(aa[u].x), al = __uint_as_float(aa[u].y);
+                        const f32x2 as2 = {as, as}, al2 = {al, al};
+#pragma unroll
+                        for (int i = 0; i < VEC / 2; ++i) {
+                            acc[i] = __builtin_elementwise_fma(val[i], as2, acc[i]);
+                            macc[tb + u][i] = __builtin_elementwise_fma(val[i], al2, macc[tb + u][i]);
+                        }
                     }
                 }
             }
 #pragma unroll
             for (int t = 0; t < G; ++t)
-                if (active && p0 + t < P) VecIO<ST, VEC>::st(mk + (size_t)(p0 + t) * HC, macc[t]);
+                if (active && p0 + t < P) row_store<ST, VEC, PSB>(mk + (size_t)(p0 + t) * HC, macc[t]);
         }
     }
     if (active) {
         if constexpr (INST && std::is_same<ST, float>::value) {
             if (gridDim.y > 1) {                   // split points: out was zero-filled by the host
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) atomic_add(out + qh * C + slot * VEC + c, acc[c]);
+                for (int i = 0; i < VEC / 2; ++i) {
+                    // channel of pair i: piece (2 i / 4), position (2 i % 4) inside it
+                    float *o = out + qh * C + slot * LCH + (2 * i / 4) * (PSB / 4) + (2 * i) % 4;
+                    atomic_add(o, acc[i].x);
+                    atomic_add(o + 1, acc[i].y);
+                }
                 return;
             }
         }
-        VecIO<ST, VEC>::st(out + qh * C + slot * VEC, acc);
+        row_store<ST, VEC, PSB>(out + qh * C + slot * LCH, acc);
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // backward, point gradients only (grad_loc, grad_weight[s]); grad_value is boxattn_binned.h
 // ---------------------------------------------------------------------------------------
-template <typename ST, int G, bool INST>
+template <typename ST, int G, bool INST, int U, int VEC>
 __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -219,21 +393,23 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     int Lq, int P, float *__restrict__ grad_loc, float *__restrict__ grad_sp,
     float *__restrict__ grad_lv, size_t n_qh, unsigned value_bytes)
 {
-    constexpr int VEC = 4, C = VEC * G, PAIRS = kWave / G;
+    constexpr int C = VEC * G, PAIRS = kWave / G;
+    typedef GeoTile<G, 1> Tile;                      // offsets only: the weights stay with lane t
+    typedef Row<ST, VEC> RowT;
+    constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;    // bytes between a lane's pieces
+    constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);   // channels of one piece
     __shared__ LevelTable lv;
-    __shared__ __attribute__((aligned(16))) GeoBox geo_all[4][kWave + kWave / G];
+    __shared__ u32x4_t geo_all[4][Tile::kSize];
     load_levels(lv, shapes, lsi, L);
 
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    GeoBox *geo = geo_all[wv];
+    u32x4_t *geo = geo_all[wv] + Tile::base(lane);
     const size_t wave = (size_t)bid * (blockDim.x / kWave) + wv;
     size_t qh = wave * PAIRS + lane / G;
     const bool active = qh < n_qh;
     if (!active) qh = n_qh - 1;
     const int slot = lane % G;
-    const int grp0 = (lane & ~(G - 1)) + lane / G;  // padded tile index of the group's slot 0
-    const int myslot = grp0 + lane % G;
     const int h = (int)(qh % H);
     const size_t bq = qh / H;
     const unsigned b = (unsigned)(bq / Lq);
@@ -242,78 +418,91 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const size_t pt0 = qh * LP;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(value), 0, value_bytes, 0x00020000);
-    const unsigned lane_off = (unsigned)(slot * VEC * sizeof(ST));
+    const unsigned lane_off = (unsigned)(slot * RowT::kLaneBytes);
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    const float rcp_p = 1.0f / (float)P;             // (n + 0.5) * rcp_p truncates to n / P
 
-    float g[VEC];
-    VecIO<ST, VEC>::ld(grad_out + qh * C + slot * VEC, g);
+    RowT g;
+    row_load<ST, VEC, PSB>(grad_out + qh * C + slot * LCH, g);
 
     // gridDim.y workgroups share the point tiles of a pair (few queries x many points)
     const int tiles = (LP + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
     const int t_begin = (int)blockIdx.y * tps * G, t_end = min(LP, t_begin + tps * G);
+    float2 xy_n = loc2[pt0 + min(t_begin + slot, LP - 1)];      // first tile
+    float as_n = w_sp[pt0 + min(t_begin + slot, LP - 1)];
+    float al_n = INST ? w_lv[pt0 + min(t_begin + slot, LP - 1)] : 0.f;
     for (int t0 = t_begin; t0 < t_end; t0 += G) {
         // ---- step A (the lane keeps its point's geometry in registers for the finish)
         const int lp = t0 + slot;
         const bool have = lp < LP;
         const int lq = have ? lp : LP - 1;
-        const int l = lq / P;
-        const float2 xy = loc2[pt0 + lq];
-        const float as = w_sp[pt0 + lq];
-        const float al = INST ? w_lv[pt0 + lq] : 0.f;
-        const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
-        GeoBox gg;
-        corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, gg.off);
-        gg.w[0] = s.hh * s.hw; gg.w[1] = s.hh * s.lw; gg.w[2] = s.lh * s.hw; gg.w[3] = s.lh * s.lw;
-        if (!have) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) gg.off[k] = kOobOffset;
+        const int l = (int)(((float)lq + 0.5f) * rcp_p);           // lq / P (exact, see rcp_p)
+        float2 xy;
+        float as, al;
+        if constexpr (kGatherPrefetch) {
+            xy = xy_n; as = as_n; al = al_n;
+            const int nq = min(lp + G, LP - 1);
+            xy_n = loc2[pt0 + nq];
+            as_n = w_sp[pt0 + nq];
+            al_n = INST ? w_lv[pt0 + nq] : 0.f;
+        } else {
+            xy = loc2[pt0 + lq];
+            as = w_sp[pt0 + lq];
+            al = INST ? w_lv[pt0 + lq] : 0.f;
         }
+        const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
+        const u32x4_t myoff =
+            corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
         wave_lds_sync();
-        geo[myslot] = gg;
+        geo[slot] = myoff;
         wave_lds_sync();
 
         // ---- step B: corner sums of the G points of this lane's pair
         float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;         // S_k of "my" point (slot)
         float m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;         // instance: sums with grad_mask
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
-            const GeoBox q = geo[grp0 + t];
-            float v[4][VEC];
+        for (int tb = 0; tb < G; tb += U) {
+            RowT v[U][4], gm[INST ? U : 1];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) BufLd<ST>::ld(rs, q.off[k] + lane_off, v[k]);
-            float a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) {
-                a1 += g[c] * v[0][c]; a2 += g[c] * v[1][c];
-                a3 += g[c] * v[2][c]; a4 += g[c] * v[3][c];
-            }
-            a1 = group_sum<G>(a1); a2 = group_sum<G>(a2);
-            a3 = group_sum<G>(a3); a4 = group_sum<G>(a4);
-            const bool mine = slot == t;
-            s1 = mine ? a1 : s1; s2 = mine ? a2 : s2; s3 = mine ? a3 : s3; s4 = mine ? a4 : s4;
-            if constexpr (INST) {
-                // grad_mask row of point (t0 + t): its p is uniform inside the group
-                const int lpt = min(t0 + t, LP - 1);
-                const int pt = lpt % P;
-                float gm[VEC];
-                VecIO<ST, VEC>::ld(grad_mask + (bq * P + pt) * HC + (size_t)h * C + slot * VEC, gm);
-                float b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f;
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    b1 += gm[c] * v[0][c]; b2 += gm[c] * v[1][c];
-                    b3 += gm[c] * v[2][c]; b4 += gm[c] * v[3][c];
+            for (int u = 0; u < U; ++u) {
+                const u32x4_t off = geo[tb + u];
+                row_load<ST, VEC, PSB>(rs, off.x + lane_off, v[u][0]);
+                row_load<ST, VEC, PSB>(rs, off.y + lane_off, v[u][1]);
+                row_load<ST, VEC, PSB>(rs, off.z + lane_off, v[u][2]);
+                row_load<ST, VEC, PSB>(rs, off.w + lane_off, v[u][3]);
+                if constexpr (INST) {
+                    // grad_mask row of point (t0 + t): its p is uniform inside the group
+                    const int lpt = min(t0 + tb + u, LP - 1);
+                    const int pt = lpt - (int)(((float)lpt + 0.5f) * rcp_p) * P;   // lpt % P
+                    row_load<ST, VEC, PSB>(grad_mask + (bq * P + pt) * HC + (size_t)h * C + slot * LCH,
+                                      gm[u]);
                 }
-                b1 = group_sum<G>(b1); b2 = group_sum<G>(b2);
-                b3 = group_sum<G>(b3); b4 = group_sum<G>(b4);
-                m1 = mine ? b1 : m1; m2 = mine ? b2 : m2; m3 = mine ? b3 : m3; m4 = mine ? b4 : m4;
+            }
+            loads_issued();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float a1 = group_sum<G>(row_dot<ST, VEC>(g, v[u][0]));
+                const float a2 = group_sum<G>(row_dot<ST, VEC>(g, v[u][1]));
+                const float a3 = group_sum<G>(row_dot<ST, VEC>(g, v[u][2]));
+                const float a4 = group_sum<G>(row_dot<ST, VEC>(g, v[u][3]));
+                const bool mine = slot == tb + u;
+                s1 = mine ? a1 : s1; s2 = mine ? a2 : s2; s3 = mine ? a3 : s3; s4 = mine ? a4 : s4;
+                if constexpr (INST) {
+                    const float b1 = group_sum<G>(row_dot<ST, VEC>(gm[u], v[u][0]));
+                    const float b2 = group_sum<G>(row_dot<ST, VEC>(gm[u], v[u][1]));
+                    const float b3 = group_sum<G>(row_dot<ST, VEC>(gm[u], v[u][2]));
+                    const float b4 = group_sum<G>(row_dot<ST, VEC>(gm[u], v[u][3]));
+                    m1 = mine ? b1 : m1; m2 = mine ? b2 : m2; m3 = mine ? b3 : m3; m4 = mine ? b4 : m4;
+                }
             }
         }
         // ---- finish: lane (pair, slot) owns point t0 + slot
         if (active && have) {
             const size_t i = pt0 + lp;
             const float Wl = (float)lv.w[l], Hl = (float)lv.h[l];
+            const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
             float gs, gx, gy;
-            gs = gg.w[0] * s1 + gg.w[1] * s2 + gg.w[2] * s3 + gg.w[3] * s4;
+            gs = w1 * s1 + w2 * s2 + w3 * s3 + w4 * s4;
             if constexpr (!INST) {
                 gx = Wl * as * (s.hh * (s2 - s1) + s.lh * (s4 - s3));
                 gy = Hl * as * (s.hw * (s3 - s1) + s.lw * (s4 - s2));
@@ -322,8 +511,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                 const float t3 = as * s3 + al * m3, t4 = as * s4 + al * m4;
                 gx = Wl * (s.hh * (t2 - t1) + s.lh * (t4 - t3));
                 gy = Hl * (s.hw * (t3 - t1) + s.lw * (t4 - t2));
-                grad_lv[i] = s.inside ? gg.w[0] * m1 + gg.w[1] * m2 + gg.w[2] * m3 + gg.w[3] * m4
-                                      : 0.f;
+                grad_lv[i] = s.inside ? w1 * m1 + w2 * m2 + w3 * m3 + w4 * m4 : 0.f;
             }
             grad_sp[i] = s.inside ? gs : 0.f;
             reinterpret_cast<float2 *>(grad_loc)[i] =

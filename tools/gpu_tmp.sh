@@ -1,0 +1,3 @@
+bash tools/gpu_variants.sh
+bash tools/gpu_variants.sh --inputs test
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
