@@ -39,7 +39,22 @@ struct BinLevel {
     int H, W, start;      // level geometry, first pixel row inside S
     int nbx, nby;         // blocks along x / y
     int blk0;             // first block id of this level inside a slice
+    unsigned mw, mh;      // floor(2^32 / W) + 1, floor(2^32 / H) + 1 (0 for sizes <= 1): blk_of()
 };
+
+// Blocks are a BALANCED partition of the map: block column c covers
+// x in [ceil(c W / nbx), ceil((c + 1) W / nbx)) with nbx = ceil(W / 8), i.e. widths differ by at
+// most one and never exceed 8 (rows alike with 4).  Fixed 8x4 tiles would leave a sliver at the
+// right / bottom edge (25 = 8 + 8 + 8 + 1): a block with 1-5 live pixels whose lanes each walk
+// lists 6-30x the usual length, and those few work items set the length of the whole kernel.
+//   block of coordinate x = floor(x nb / size), by multiply-high with the precomputed magic
+//   (exact for x nb < 2^32 / size, which the host checks).
+__device__ __forceinline__ int blk_of(int x, int nb, unsigned magic)
+{
+    return (int)__umulhi((unsigned)__mul24(x, nb), magic);
+}
+// first coordinate of block c: ceil(c size / nb)
+__device__ __forceinline__ int blk_lo(int c, int size, int nb) { return (c * size + nb - 1) / nb; }
 
 #ifndef BOXATTN_TUNE_INTERLEAVE
 #define BOXATTN_TUNE_INTERLEAVE 1
@@ -67,8 +82,9 @@ __device__ __forceinline__ void touched_blocks(const Sample<float> &s, const Bin
 {
     const bool ya = s.ok[0] || s.ok[1], yb = s.ok[2] || s.ok[3];
     const bool xa = s.ok[0] || s.ok[2], xb = s.ok[1] || s.ok[3];
-    const int ra = s.y0 / BH, rb = (s.y0 + 1) / BH;          // only used when the row is valid
-    const int ca = s.x0 / BW, cb = (s.x0 + 1) / BW;
+    // only used when the row / column is valid
+    const int ra = blk_of(s.y0, lv.nby, lv.mh), rb = blk_of(s.y0 + 1, lv.nby, lv.mh);
+    const int ca = blk_of(s.x0, lv.nbx, lv.mw), cb = blk_of(s.x0 + 1, lv.nbx, lv.mw);
     const bool use_rb = yb && (!ya || rb != ra);             // second row adds a new block row
     const bool use_cb = xb && (!xa || cb != ca);
     const int base_a = lv.blk0 + ra * lv.nbx, base_b = lv.blk0 + rb * lv.nbx;
@@ -79,10 +95,14 @@ __device__ __forceinline__ void touched_blocks(const Sample<float> &s, const Bin
 }
 
 // ---------------------------------------------------------------------------------------
-// 1 + 3: count / fill.  grid = (query chunks, slices), block 256, dynamic LDS 2*nblk ints.
+// 1 + 3: count / fill.  grid = (workgroups, slices), block kBinThreads, dynamic LDS nblk+1 ints.
 // ---------------------------------------------------------------------------------------
+#ifndef BOXATTN_TUNE_BIN_THREADS
+#define BOXATTN_TUNE_BIN_THREADS 512
+#endif
+constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
 template <int BW, int BH, bool FILL>
-__global__ __launch_bounds__(256) void bin_kernel(const float *__restrict__ loc, BinPlan plan,
+__global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc, BinPlan plan,
                                                   int H, int Lq, int P, int q_per_wg,
                                                   int *__restrict__ part,
                                                   const int *__restrict__ subtot,
@@ -272,8 +292,15 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
 //    grid = (waves per slice, slices); waves are persistent and pull items from the slice's
 //    queue.  A block is 8x4 pixels; in the summation phase lane = (pixel, channel half).
 // ---------------------------------------------------------------------------------------
+#ifndef BOXATTN_TUNE_ABLATE
+#define BOXATTN_TUNE_ABLATE 0      // timing experiments only (wrong results): 1 no list walk,
+#endif                             // 2 no ranks / entries, 3 no row fetch + stage, 4 walk without row reads
+#ifndef BOXATTN_TUNE_ACC_WPE
+#define BOXATTN_TUNE_ACC_WPE 1
+#endif
 template <typename ST, int C, bool INST, int RPL = 1>
-__global__ __launch_bounds__(64) void binned_accumulate_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BOXATTN_TUNE_ACC_WPE)))
+void binned_accumulate_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask,
     const float *__restrict__ loc, const float *__restrict__ w_sp,
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const int *__restrict__ n_items, const int *__restrict__ records,
     ST *__restrict__ grad_value, float *__restrict__ partials)
 {
-    constexpr int BW = 8, BH = 4, PB = 32;
+    constexpr int BW = 8, PB = 32;                      // blocks: up to 8 x 4 pixels
     constexpr int R = 64 * RPL;                        // records per round, RPL per lane
     constexpr int CH = C / 2;                          // channels per lane while summing
     constexpr int ROWB = C * (int)sizeof(ST);          // bytes of one upstream-gradient row
@@ -293,7 +320,10 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     constexpr int RPP = 64 / LPR;                      // rows staged per pass
     constexpr int NPASS = R / RPP;                     // staging passes per round
     constexpr int EPL = 16 / (int)sizeof(ST);          // elements per fetched 16-byte piece
-    constexpr int UNR = 2;                             // list entries handled per step
+#ifndef BOXATTN_TUNE_UNR
+#define BOXATTN_TUNE_UNR 2
+#endif
+    constexpr int UNR = BOXATTN_TUNE_UNR;              // list entries handled per step
     typedef typename std::conditional<INST, float4, float2>::type Entry;   // {w*a_s[, w*a_l], j}
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector: stays in VGPRs
     constexpr int NQ = CH * SB / 16;                   // 16-byte pieces of a lane's half row
@@ -333,6 +363,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
     const int n_it = n_items[2 * s];
     const int lp_mask = (1 << plan.lp_bits) - 1;
 
+    if (lane <= PB) pcnt[lane] = 0;
     for (int i = lane; i < RS / 4; i += 64) {          // the zero rows
         reinterpret_cast<int *>(&gstage[R * RS])[i] = 0;
         if constexpr (INST) reinterpret_cast<int *>(&mstage[R * RS])[i] = 0;
@@ -353,7 +384,8 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         for (int k = 1; k < kMaxBinLevels; ++k)
             if (k < plan.L && blk >= plan.lv[k].blk0) lv = plan.lv[k];
         const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
-        const int oy = by * BH, ox = bx * BW;
+        const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
+        const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
         const int *rec = records + (size_t)s * plan.rec_cap +
                          offsets[(size_t)s * (plan.nblk + 1) + blk];
         f32x2 acc[CH / 2];                           // channel pairs (2i, 2i+1) of this half
@@ -411,21 +443,19 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #pragma unroll
         for (int i = 0; i < RPL; ++i) { xy_n[i] = make_float2(0.f, 0.f); as_n[i] = al_n[i] = 0.f; }
         fetch_point(fetch_ids(item.y), xy_c, as_c, al_c);
-        BOXATTN_FETCH_ROWS()
+        if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_FETCH_ROWS() }
         Ids rec_n = fetch_ids(item.y + R);
-        BOXATTN_STAGE_ROWS()                           // round 0 staged directly
+        if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS() }   // round 0 staged directly
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;         // wave-uniform
             if (more) {                                // issue everything round r+1 needs
                 fetch_point(rec_n, xy_n, as_n, al_n);
-                BOXATTN_FETCH_ROWS()
+                if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_FETCH_ROWS() }
                 rec_n = fetch_ids(rr + 2 * R);
             }
-            if (lane <= PB) pcnt[lane] = 0;
-            wave_lds_sync();
             // ---- phase 1: lane = RPL records: geometry, rank inside the destination pixel
-            //      lists.  Branch-free: corners outside this block go to dump slots.
+            //      lists (pixk == PB: corner not in this block / idle lane).
             float wk[RPL][4];
             int pixk[RPL][4], rank[RPL][4];
 #pragma unroll
@@ -436,18 +466,26 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
-                    const bool use = i * 64 + lane < n && sm.ok[k] && (yy >> 2) == by &&
-                                     (xx >> 3) == bx;
+                    const bool use = i * 64 + lane < n && sm.ok[k] &&
+                                     (unsigned)(yy - oy) < (unsigned)bh &&
+                                     (unsigned)(xx - ox) < (unsigned)bw;
                     pixk[i][k] = use ? (yy - oy) * BW + (xx - ox) : PB;
                 }
             }
+            // predicated, not redirected to a dump counter: same-address LDS atomics serialise per
+            // lane, and a third of the corners (other blocks, idle lanes) would all hit the dump
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rank[i][k] = atomicAdd(&pcnt[pixk[i][k]], 1);
+                for (int k = 0; k < 4; ++k) {
+                    rank[i][k] = 0;
+                    if (BOXATTN_TUNE_ABLATE != 2 && pixk[i][k] < PB)
+                        rank[i][k] = atomicAdd(&pcnt[pixk[i][k]], 1);
+                }
             wave_lds_sync();
             {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips)
                 int ic = lane < PB ? pcnt[lane] : 0;
+                if (lane < PB) pcnt[lane] = 0;                  // ready for the next round
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x111, 0xF, 0xF, true);   // row_shr:1
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x112, 0xF, 0xF, true);   // row_shr:2
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x114, 0xF, 0xF, true);   // row_shr:4
@@ -457,16 +495,23 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                 if (lane == 0) poff[0] = 0;
             }
             wave_lds_sync();
+            // all list offsets first (one LDS round trip), then the predicated entry writes
+            int epos[RPL][4];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) epos[i][k] = poff[pixk[i][k]] + rank[i][k];
 #pragma unroll
             for (int i = 0; i < RPL; ++i)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int e = pixk[i][k] < PB ? poff[pixk[i][k]] + rank[i][k] : 4 * R + UNR;
+                    if (BOXATTN_TUNE_ABLATE == 2 || pixk[i][k] >= PB) continue;
                     const float slot = __int_as_float(i * 64 + lane);
                     if constexpr (INST)
-                        ent[e] = make_float4(wk[i][k] * as_c[i], wk[i][k] * al_c[i], slot, 0.f);
+                        ent[epos[i][k]] =
+                            make_float4(wk[i][k] * as_c[i], wk[i][k] * al_c[i], slot, 0.f);
                     else
-                        ent[e] = make_float2(wk[i][k] * as_c[i], slot);
+                        ent[epos[i][k]] = make_float2(wk[i][k] * as_c[i], slot);
                 }
             wave_lds_sync();
             // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
@@ -476,7 +521,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             Entry en_n[UNR];                           // entries of the next step (prefetched)
 #pragma unroll
             for (int u = 0; u < UNR; ++u) en_n[u] = ent[e0 + u];
-            for (int e = e0; e < e1; e += UNR) {
+            for (int e = e0; e < (BOXATTN_TUNE_ABLATE == 1 ? e0 : e1); e += UNR) {
                 Entry en[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -504,7 +549,8 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
                     const u32x4 *gp = reinterpret_cast<const u32x4 *>(
                         &gstage[jj[u] * RS + half * (CH * SB)]);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) rw[u][q] = gp[q];
+                    for (int q = 0; q < NQ; ++q)
+                        rw[u][q] = BOXATTN_TUNE_ABLATE == 4 ? u32x4{(unsigned)jj[u], 1u, 2u, 3u} : gp[q];
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -532,7 +578,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
             }
             wave_lds_sync();
             if (more) {                                // stage round r+1 (rows have arrived)
-                BOXATTN_STAGE_ROWS()
+                if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS() }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) { xy_c[i] = xy_n[i]; as_c[i] = as_n[i]; al_c[i] = al_n[i]; }
             }
@@ -545,7 +591,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_kernel(
         //      anywhere.
         if (item.w < 0) {
             const int yy = oy + mypix / BW, xx = ox + mypix % BW;
-            if (yy < lv.H && xx < lv.W) {
+            if (mypix / BW < bh && mypix % BW < bw) {
                 ST *dst = grad_value +
                           (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
                           half * CH;
@@ -581,7 +627,7 @@ __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__rest
                                                               BinPlan plan, int S, int H,
                                                               ST *__restrict__ grad_value)
 {
-    constexpr int BW = 8, BH = 4, PB = 32, CH = C / 2, EPL = 16 / (int)sizeof(ST);
+    constexpr int BW = 8, PB = 32, CH = C / 2, EPL = 16 / (int)sizeof(ST);
     const int s = blockIdx.y, b = s / H, h = s % H;
     const int n_comb = n_items[2 * s + 1];
     const int mypix = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -592,8 +638,10 @@ __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__rest
         for (int k = 1; k < kMaxBinLevels; ++k)
             if (k < plan.L && cb.x >= plan.lv[k].blk0) lv = plan.lv[k];
         const int by = (cb.x - lv.blk0) / lv.nbx, bx = (cb.x - lv.blk0) % lv.nbx;
-        const int yy = by * BH + mypix / BW, xx = bx * BW + mypix % BW;
-        if (yy >= lv.H || xx >= lv.W) continue;
+        const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
+        const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
+        if (mypix / BW >= bh || mypix % BW >= bw) continue;
+        const int yy = oy + mypix / BW, xx = ox + mypix % BW;
         float acc[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[c] = 0.f;

@@ -93,10 +93,16 @@ template <typename ST, int G, int VEC> struct GatherUnroll {
     static constexpr int want = VEC == 8 ? u8 : u4;
     static constexpr int value = (want <= 0 || want > G) ? G : want;
 };
+// (the 8-channel kernels are only instantiated for the storage types that select them)
+template <typename ST> struct GatherVec8 {
+    static constexpr bool value = (sizeof(ST) == 2 ? BOXATTN_TUNE_VEC_BF16 : BOXATTN_TUNE_VEC_F32) == 8;
+};
 #define BOXATTN_GATHER_DISPATCH(cfg, X)                                                       \
     do {                                                                                      \
         if ((cfg).VEC == 8) {                                                                 \
-            if ((cfg).G == 4) { X(4, 8) } else { X(8, 8) }                                    \
+            if constexpr (GatherVec8<ST>::value) {                                            \
+                if ((cfg).G == 4) { X(4, 8) } else { X(8, 8) }                                \
+            }                                                                                 \
         } else if ((cfg).G == 4) { X(4, 4) } else if ((cfg).G == 8) { X(8, 4) } else { X(16, 4) } \
     } while (0)
 
@@ -397,6 +403,12 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
         p.lv[l].start = (int)st;
         p.lv[l].nbx = (int)((wl + BW - 1) / BW);
         p.lv[l].nby = (int)((hl + BH - 1) / BH);
+        // blk_of(): floor(x nb / size) by multiply-high is exact while x nb < 2^32 / size
+        if ((unsigned long long)wl * wl * p.lv[l].nbx >= (1ull << 32) ||
+            (unsigned long long)hl * hl * p.lv[l].nby >= (1ull << 32))
+            return false;
+        p.lv[l].mw = wl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)wl + 1) : 0u;
+        p.lv[l].mh = hl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)hl + 1) : 0u;
         p.lv[l].blk0 = (int)blk0;
         blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
     }
@@ -431,7 +443,8 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
     WsLayout w;
     // ~2048 workgroups for the two binning passes
     // ... and at most kScanSub * kScanWgPerSub workgroups per slice (bin_scan_a_kernel)
-    w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + 2047) / 2048));
+    const long long wg_target = 2048ll * 256 / kBinThreads;   // ~8 waves per SIMD over the chip
+    w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
     w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
                                           (kScanSub * kScanWgPerSub));
     w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
@@ -462,13 +475,13 @@ inline void launch_binning(const float *loc, const Dims &d, const BinPlan &plan,
     const dim3 bgrid(w.n_wg, ns);
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
-    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(256), bsh, st, loc, plan, d.H, d.Lq,
+    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
                        d.P, w.q_per_wg, part, subtot, offsets, records);
     hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
                        subtot, plan);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items, combos,
                        n_items, plan);
-    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(256), bsh, st, loc, plan, d.H, d.Lq,
+    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
                        d.P, w.q_per_wg, part, subtot, offsets, records);
 }
 
@@ -525,7 +538,13 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
         // two records per lane and round pay off for bf16 box attention (fewer rounds: 141 ->
         // 126 us); fp32 and the instance flavour run out of registers / LDS with it
-        constexpr int kRpl = (sizeof(ST) == 2 && !INST) ? 2 : 1;
+#ifndef BOXATTN_TUNE_RPL_BF16
+#define BOXATTN_TUNE_RPL_BF16 2
+#endif
+#ifndef BOXATTN_TUNE_RPL_F32
+#define BOXATTN_TUNE_RPL_F32 1
+#endif
+        constexpr int kRpl = INST ? 1 : (sizeof(ST) == 2 ? BOXATTN_TUNE_RPL_BF16 : BOXATTN_TUNE_RPL_F32);
         hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
                            dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
                            d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);

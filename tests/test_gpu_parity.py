@@ -172,6 +172,10 @@ SEEDED = [
     ([(9, 7), (4, 3)], 2, 2, 64, 21, 9),                          # G=16 path, odd P
     ([(9, 7), (4, 3)], 2, 3, 12, 5, 4),                           # C%4==0 but no fast variant
     ([(6, 5)], 1, 1, 1, 3, 1),                                    # minimum everything
+    # odd map sizes (uneven destination blocks), one-pixel-wide / -high levels, enough points
+    # per block for chunked work items
+    ([(25, 25), (13, 13), (7, 5), (1, 3), (2, 1)], 1, 2, 32, 700, 4),
+    ([(13, 21), (5, 4)], 2, 2, 64, 300, 9),                       # 8 channels per lane, G=8 (bf16)
 ]
 
 

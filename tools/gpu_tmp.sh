@@ -1,3 +1,2 @@
 bash tools/gpu_variants.sh
-bash tools/gpu_variants.sh --inputs test
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4

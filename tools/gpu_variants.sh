@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for lib in boxer_amd/variants/libboxattn_*.so; do
   name=$(basename $lib .so); name=${name#libboxattn_}
-  for dt in bf16 fp32; do
+  for dt in ${VARIANT_DTYPES:-bf16 fp32}; do
     BOXATTN_HIP_LIB=$PWD/$lib timeout 300 python bench.py --steps 30 --warmup 5 --dtype $dt --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
 import json,sys
 try:
