@@ -307,6 +307,8 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--inputs", default="model", choices=["model", "test"])
+    ap.add_argument("--batch", type=int, default=BATCH,
+                    help="images per GPU (the headline line uses the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
     args = ap.parse_args()
@@ -329,7 +331,8 @@ def main():
     _lib.set_variant(args.variant)
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     # every rank owns its own images (different seed): data-parallel shard, no exchange
-    inp = make_inputs(args.workload, dtype, device, family=args.inputs, seed=rank)
+    inp = make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch,
+                      seed=rank)
     step = make_step(inp)
 
     elapsed = run_timed(step, args.steps, args.warmup, torch.cuda.synchronize, dist, device)
@@ -384,7 +387,7 @@ def main():
                                    "B=%d images per GPU, inputs=%s" % (
                                        args.workload, inp["kind"],
                                        "/".join("%dx%d" % hw for hw in WORKLOADS[args.workload][0]),
-                                       inp["dims"]["Lq"], H_HEADS, C_HEAD, inp["dims"]["P"], BATCH,
+                                       inp["dims"]["Lq"], H_HEADS, C_HEAD, inp["dims"]["P"], args.batch,
                                        args.inputs),
                        "points_per_step_per_gpu": np_rank, "parallelism": "dp%d" % world},
             "roofline": roofline,

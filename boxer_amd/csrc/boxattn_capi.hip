@@ -539,7 +539,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         // two records per lane and round pay off for bf16 box attention (fewer rounds: 141 ->
         // 126 us); fp32 and the instance flavour run out of registers / LDS with it
 #ifndef BOXATTN_TUNE_RPL_BF16
-#define BOXATTN_TUNE_RPL_BF16 2
+#define BOXATTN_TUNE_RPL_BF16 1
 #endif
 #ifndef BOXATTN_TUNE_RPL_F32
 #define BOXATTN_TUNE_RPL_F32 1

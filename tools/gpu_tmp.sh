@@ -1,2 +1,1 @@
-bash tools/gpu_variants.sh
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+VARIANT_DTYPES=bf16 bash tools/gpu_variants.sh
