@@ -93,6 +93,18 @@ template <typename ST, int G, int VEC> struct GatherUnroll {
     static constexpr int want = VEC == 8 ? u8 : u4;
     static constexpr int value = (want <= 0 || want > G) ? G : want;
 };
+inline unsigned div_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / d); }
+// index constants of the gather kernels; false if the problem is outside their 32-bit arithmetic
+inline bool gather_idx(const Dims &d, GatherIdx &ix)
+{
+    const size_t n_qh = d.n_qh();
+    if (n_qh >= (1ull << 31) || (size_t)d.B * d.S >= (1ull << 31)) return false;
+    ix.n_qh = (unsigned)n_qh;
+    ix.magic_h = div_magic((unsigned)d.H);
+    ix.magic_lq = div_magic((unsigned)d.Lq);
+    ix.rcp_p = 1.0f / (float)d.P;
+    return true;
+}
 // (the 8-channel kernels are only instantiated for the storage types that select them)
 template <typename ST> struct GatherVec8 {
     static constexpr bool value = (sizeof(ST) == 2 ? BOXATTN_TUNE_VEC_BF16 : BOXATTN_TUNE_VEC_F32) == 8;
@@ -191,7 +203,8 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
         if (fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out,
                         out)) {
             const size_t vbytes = d.n_value() * sizeof(ST);
-            const bool gen2 = g_variant != 2 && vbytes < kOobOffset;   // buffer-load kernels
+            GatherIdx ix{};
+            const bool gen2 = g_variant != 2 && vbytes < kOobOffset && gather_idx(d, ix);   // buffer-load kernels
             const GatherCfg cfg =
                 gen2 ? gather_cfg<ST>(d, aligned(value, 16) && aligned(out, 16) &&
                                          (!INST || aligned(mask, 16)))
@@ -213,7 +226,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 #define BOXATTN_FWD2(GG, VV)                                                                  \
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
                        dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
-                       w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, n_qh, (unsigned)vbytes);
+                       w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, ix, (unsigned)vbytes);
                 BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2);
 #undef BOXATTN_FWD2
             } else {
@@ -507,7 +520,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
         const size_t n_qh = d.n_qh();
         const size_t vbytes = d.n_value() * sizeof(ST);
-        if (vbytes < kOobOffset) {
+        GatherIdx ix{};
+        if (vbytes < kOobOffset && gather_idx(d, ix)) {
             const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
                                                     (!INST || aligned(grad_mask, 16)));
             const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / cfg.G) * 4);
@@ -516,7 +530,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
                        dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
                        w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
-                       grad_lv, n_qh, (unsigned)vbytes);
+                       grad_lv, ix, (unsigned)vbytes);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
 #undef BOXATTN_PG2
         } else {

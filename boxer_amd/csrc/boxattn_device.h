@@ -164,6 +164,14 @@ __device__ __forceinline__ void divmod_small(int n, int d, float rcp, int &q, in
     if (r < 0) { --q; r += d; }
     if (r >= d) { ++q; r -= d; }
 }
+// n / d and n % d for n < 2^31 with magic = floor(2^32 / d) from the host (0xFFFFFFFF for d = 1):
+// the multiply-high estimate is the quotient or one less, fixed by one compare.
+__device__ __forceinline__ void divmod_magic(unsigned n, unsigned d, unsigned magic, unsigned &q,
+                                             unsigned &r) {
+    q = __umulhi(n, magic);
+    r = n - q * d;
+    if (r >= d) { ++q; r -= d; }
+}
 // level of flattened point index lp = l * P + p: a compare chain instead of a division
 __device__ __forceinline__ int level_of(int lp, int P, int L) {
     int l = 0;

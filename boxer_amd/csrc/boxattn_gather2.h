@@ -165,6 +165,32 @@ __device__ __forceinline__ void row_store(ST *p, const f32x2 (&acc)[VEC / 2])
     }
 }
 
+// G == 4: a pair is one DPP quad, so lane (j, t)'s step-A registers reach the other lanes of the
+// pair with quad_perm broadcasts (VALU moves the compiler folds into the consuming add where it
+// can) -- no LDS tile, no LDS round trip between the two steps.
+#ifndef BOXATTN_TUNE_QUAD_DPP
+#define BOXATTN_TUNE_QUAD_DPP 1
+#endif
+template <int G> struct UseQuadDpp { static constexpr bool value = G == 4 && BOXATTN_TUNE_QUAD_DPP; };
+template <int CTRL> __device__ __forceinline__ unsigned dpp_mov(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned quad_bcast(unsigned v, int t)   // t is a constant after unrolling
+{
+    switch (t & 3) {
+    case 0: return dpp_mov<0x00>(v);
+    case 1: return dpp_mov<0x55>(v);
+    case 2: return dpp_mov<0xAA>(v);
+    default: return dpp_mov<0xFF>(v);
+    }
+}
+__device__ __forceinline__ u32x4_t quad_bcast(u32x4_t v, int t)
+{
+    u32x4_t r = {quad_bcast(v.x, t), quad_bcast(v.y, t), quad_bcast(v.z, t), quad_bcast(v.w, t)};
+    return r;
+}
+
 // The wave-private geometry tile: per point NH 16-byte pieces {4 offsets}{4 weights}[{as, al}],
 // one 16-byte pad per G-lane group so that the groups' broadcast reads start on different banks.
 template <int G, int NH> struct GeoTile {
@@ -195,6 +221,15 @@ __device__ __forceinline__ u32x4_t as_u32x4(float a, float b, float c, float d)
     return r;
 }
 
+// Host-computed constants of the index arithmetic (no 64-bit divisions in the kernels: they were
+// a fifth of the instructions of a wave).
+struct GatherIdx {
+    unsigned n_qh;        // B * Lq * H  (< 2^31)
+    unsigned magic_h;     // floor(2^32 / H)   (divmod_magic)
+    unsigned magic_lq;    // floor(2^32 / Lq)
+    float rcp_p;          // 1.0f / P
+};
+
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
-    int P, ST *__restrict__ out, ST *__restrict__ mask, size_t n_qh, unsigned value_bytes)
+    int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes)
 {
     constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
     typedef GeoTile<G, NH> Tile;
@@ -217,24 +252,25 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);   // this group's part of the tile
-    const size_t wave = (size_t)bid * (blockDim.x / kWave) + wv;
-    size_t qh = wave * PAIRS + lane / G;
-    const bool active = qh < n_qh;
-    if (!active) qh = n_qh - 1;
+    const unsigned wave = bid * (blockDim.x / kWave) + wv;
+    unsigned qh = wave * PAIRS + lane / G;
+    const bool active = qh < ix.n_qh;
+    if (!active) qh = ix.n_qh - 1;
     const int slot = lane % G;                      // step A: point slot; step B: channel chunk
-    const int h = (int)(qh % H);
-    const size_t bq = qh / H;
-    const unsigned b = (unsigned)(bq / Lq);
+    unsigned bq, hu, b, qu;
+    divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
+    divmod_magic(bq, (unsigned)Lq, ix.magic_lq, b, qu);
+    const int h = (int)hu;
     const size_t HC = (size_t)H * C;
     const int LP = L * P;
-    const size_t pt0 = qh * LP;
+    const size_t pt0 = (size_t)qh * LP;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(value), 0, value_bytes, 0x00020000);
     const unsigned lane_off = (unsigned)(slot * RowT::kLaneBytes);
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     // (n + 0.5) * rcp_p truncates to n / P for every n < L * P <= 2^16: the product is at least
     // 0.5 / P away from an integer, far more than the rounding error of the two operations
-    const float rcp_p = 1.0f / (float)P;
+    const float rcp_p = ix.rcp_p;
 
     f32x2 acc[VEC / 2];
 #pragma unroll
@@ -244,6 +280,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
         float2 xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
         float a_n = w_sp[pt0 + min(slot, LP - 1)];
         for (int t0 = 0; t0 < LP; t0 += G) {
+            u32x4_t my_off = {0u, 0u, 0u, 0u}, my_wt = {0u, 0u, 0u, 0u};
             {   // ---- step A
                 const int lp = t0 + slot;
                 const bool have = lp < LP;
@@ -266,20 +303,30 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                     corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
                 const u32x4_t wt = as_u32x4(s.hh * s.hw * a, s.hh * s.lw * a, s.lh * s.hw * a,
                                             s.lh * s.lw * a);
-                wave_lds_sync();                   // previous tile fully consumed
-                geo[slot * NH] = off;
-                geo[slot * NH + 1] = wt;
-                wave_lds_sync();
+                if constexpr (UseQuadDpp<G>::value) {
+                    my_off = off;
+                    my_wt = wt;
+                } else {
+                    wave_lds_sync();               // previous tile fully consumed
+                    geo[slot * NH] = off;
+                    geo[slot * NH + 1] = wt;
+                    wave_lds_sync();
+                }
             }
             // ---- step B (U points' loads in flight at a time)
-#pragma unroll 1
+#pragma unroll
             for (int tb = 0; tb < G; tb += U) {
                 u32x4_t off[U], wt[U];
                 RowT v[U][4];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    off[u] = geo[(tb + u) * NH];
-                    wt[u] = geo[(tb + u) * NH + 1];
+                    if constexpr (UseQuadDpp<G>::value) {
+                        off[u] = quad_bcast(my_off, tb + u);
+                        wt[u] = quad_bcast(my_wt, tb + u);
+                    } else {
+                        off[u] = geo[(tb + u) * NH];
+                        wt[u] = geo[(tb + u) * NH + 1];
+                    }
                     row_load<ST, VEC, PSB>(rs, off[u].x + lane_off, v[u][0]);
                     row_load<ST, VEC, PSB>(rs, off[u].y + lane_off, v[u][1]);
                     row_load<ST, VEC, PSB>(rs, off[u].z + lane_off, v[u][2]);
@@ -296,7 +343,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
             }
         }
     } else {
-        ST *mk = mask + bq * P * HC + (size_t)h * C + slot * LCH;
+        ST *mk = mask + (size_t)bq * P * HC + (size_t)h * C + slot * LCH;
         // few queries x many points (decoder, 14x14 grids): gridDim.y workgroups share the
         // point tiles of a (query, head) pair; out is then accumulated with atomics
         const int tiles = (P + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -370,14 +417,14 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
 #pragma unroll
                 for (int i = 0; i < VEC / 2; ++i) {
                     // channel of pair i: piece (2 i / 4), position (2 i % 4) inside it
-                    float *o = out + qh * C + slot * LCH + (2 * i / 4) * (PSB / 4) + (2 * i) % 4;
+                    float *o = out + (size_t)qh * C + slot * LCH + (2 * i / 4) * (PSB / 4) + (2 * i) % 4;
                     atomic_add(o, acc[i].x);
                     atomic_add(o + 1, acc[i].y);
                 }
                 return;
             }
         }
-        row_store<ST, VEC, PSB>(out + qh * C + slot * LCH, acc);
+        row_store<ST, VEC, PSB>(out + (size_t)qh * C + slot * LCH, acc);
     }
 }
 
@@ -391,7 +438,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const float *__restrict__ w_sp, const float *__restrict__ w_lv,
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask, int S, int H, int L,
     int Lq, int P, float *__restrict__ grad_loc, float *__restrict__ grad_sp,
-    float *__restrict__ grad_lv, size_t n_qh, unsigned value_bytes)
+    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes)
 {
     constexpr int C = VEC * G, PAIRS = kWave / G;
     typedef GeoTile<G, 1> Tile;                      // offsets only: the weights stay with lane t
@@ -405,25 +452,26 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);
-    const size_t wave = (size_t)bid * (blockDim.x / kWave) + wv;
-    size_t qh = wave * PAIRS + lane / G;
-    const bool active = qh < n_qh;
-    if (!active) qh = n_qh - 1;
+    const unsigned wave = bid * (blockDim.x / kWave) + wv;
+    unsigned qh = wave * PAIRS + lane / G;
+    const bool active = qh < ix.n_qh;
+    if (!active) qh = ix.n_qh - 1;
     const int slot = lane % G;
-    const int h = (int)(qh % H);
-    const size_t bq = qh / H;
-    const unsigned b = (unsigned)(bq / Lq);
+    unsigned bq, hu, b, qu;
+    divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
+    divmod_magic(bq, (unsigned)Lq, ix.magic_lq, b, qu);
+    const int h = (int)hu;
     const size_t HC = (size_t)H * C;
     const int LP = L * P;
-    const size_t pt0 = qh * LP;
+    const size_t pt0 = (size_t)qh * LP;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(value), 0, value_bytes, 0x00020000);
     const unsigned lane_off = (unsigned)(slot * RowT::kLaneBytes);
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    const float rcp_p = 1.0f / (float)P;             // (n + 0.5) * rcp_p truncates to n / P
+    const float rcp_p = ix.rcp_p;                    // (n + 0.5) * rcp_p truncates to n / P
 
     RowT g;
-    row_load<ST, VEC, PSB>(grad_out + qh * C + slot * LCH, g);
+    row_load<ST, VEC, PSB>(grad_out + (size_t)qh * C + slot * LCH, g);
 
     // gridDim.y workgroups share the point tiles of a pair (few queries x many points)
     const int tiles = (LP + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -453,9 +501,11 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
         const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
         const u32x4_t myoff =
             corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
-        wave_lds_sync();
-        geo[slot] = myoff;
-        wave_lds_sync();
+        if constexpr (!UseQuadDpp<G>::value) {
+            wave_lds_sync();
+            geo[slot] = myoff;
+            wave_lds_sync();
+        }
 
         // ---- step B: corner sums of the G points of this lane's pair
         float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;         // S_k of "my" point (slot)
@@ -465,7 +515,9 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
             RowT v[U][4], gm[INST ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const u32x4_t off = geo[tb + u];
+                u32x4_t off;
+                if constexpr (UseQuadDpp<G>::value) off = quad_bcast(myoff, tb + u);
+                else off = geo[tb + u];
                 row_load<ST, VEC, PSB>(rs, off.x + lane_off, v[u][0]);
                 row_load<ST, VEC, PSB>(rs, off.y + lane_off, v[u][1]);
                 row_load<ST, VEC, PSB>(rs, off.z + lane_off, v[u][2]);
@@ -474,7 +526,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                     // grad_mask row of point (t0 + t): its p is uniform inside the group
                     const int lpt = min(t0 + tb + u, LP - 1);
                     const int pt = lpt - (int)(((float)lpt + 0.5f) * rcp_p) * P;   // lpt % P
-                    row_load<ST, VEC, PSB>(grad_mask + (bq * P + pt) * HC + (size_t)h * C + slot * LCH,
+                    row_load<ST, VEC, PSB>(grad_mask + ((size_t)bq * P + pt) * HC + (size_t)h * C + slot * LCH,
                                       gm[u]);
                 }
             }
