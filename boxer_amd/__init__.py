@@ -11,13 +11,13 @@ The compute lives in a C-ABI HIP library (``include/boxattn.h``, ``boxer_amd/csr
 DESIGN.md and INTEGRATION.md.  There is no CPU fallback: ops raise if the library is missing.
 """
 from . import _lib, ops
-from .functions import (BoxAttnBF16Function, BoxAttnFunction, InstanceAttnBF16Function,
-                        InstanceAttnFunction)
+from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
+                        InstanceAttnBF16Function, InstanceAttnFunction)
 from .modules import Box3dAttention, BoxAttention, InstanceAttention
 
 __all__ = [
     "ops", "BoxAttnFunction", "InstanceAttnFunction", "BoxAttnBF16Function",
-    "InstanceAttnBF16Function", "BoxAttention", "InstanceAttention", "Box3dAttention",
+    "InstanceAttnBF16Function", "BoxGridFunction", "BoxAttention", "InstanceAttention", "Box3dAttention",
     "build", "build_info",
 ]
 __version__ = "0.1.0"

@@ -14,7 +14,7 @@ LIB_NAME = "libboxattn_hip.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
 SOURCES = ["boxattn_capi.hip"]
 HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h", "boxattn_binned.h",
-           "boxattn_gather2.h"]
+           "boxattn_gather2.h", "boxattn_grid.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-shared", "-Wall", "-Wno-pass-failed"]
 
@@ -38,11 +38,18 @@ _WS_SIGNATURES = {
     "instattn_fwd_train": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
                                                           _vp],
 }
+_GRID_SIGNATURES = {
+    # ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios, [grad_grid,]
+    # B, Lq, H, L, P, outputs..., stream
+    "boxattn_grid_fwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp] + [_i] * 5 + [_vp, _vp],
+    "boxattn_grid_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp],
+}
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
-           "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes"] + [
+           "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
+           "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def hipcc_path():
@@ -105,6 +112,9 @@ def load():
             fn = getattr(lib, "%s_%s" % (stem, suf))
             fn.argtypes = args
             fn.restype = _i
+    for name, args in _GRID_SIGNATURES.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = _i
     lib.boxattn_bwd_workspace_bytes.argtypes = [_i] * 8 + [_vp, _vp]
     lib.boxattn_bwd_workspace_bytes.restype = ctypes.c_size_t
     if lib.boxattn_abi_version() != ABI_VERSION:

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
         if (live) {
             offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
             for (int j = 0; j < nch; ++j)
-                items[(size_t)s * plan.item_cap + ex[1] + j] =
-                    make_int4(k, j * plan.chunk, min(c, (j + 1) * plan.chunk),
+                items[(size_t)s * plan.item_cap + ex[1] + j] =     // record range inside the slice
+                    make_int4(k, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
                               nch > 1 ? ex[2] + j : -1);          // .w = partial slot or -1
             if (nch > 1)
                 combos[(size_t)s * plan.nblk + ex[3]] = make_int4(k, ex[2], nch, 0);
@@ -386,8 +386,8 @@ void binned_accumulate_kernel(
         const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
         const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
         const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
-        const int *rec = records + (size_t)s * plan.rec_cap +
-                         offsets[(size_t)s * (plan.nblk + 1) + blk];
+        const int *rec = records + (size_t)s * plan.rec_cap;   // item.y / .z index the slice
+        (void)offsets;
         f32x2 acc[CH / 2];                           // channel pairs (2i, 2i+1) of this half
 #pragma unroll
         for (int i = 0; i < CH / 2; ++i) acc[i] = f32x2{0.f, 0.f};

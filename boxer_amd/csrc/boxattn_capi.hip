@@ -16,6 +16,7 @@
 #include "boxattn_fast.h"
 #include "boxattn_gather2.h"
 #include "boxattn_generic.h"
+#include "boxattn_grid.h"
 
 using namespace boxattn;
 
@@ -386,7 +387,10 @@ struct SideStream {
 };
 
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
-constexpr int kChunk = 1024;          // records per work item
+#ifndef BOXATTN_TUNE_CHUNK
+#define BOXATTN_TUNE_CHUNK 1024
+#endif
+constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item
 constexpr size_t kSideStreamMinPoints = 1u << 20;   // below this the fork/join costs more than it hides
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
@@ -902,6 +906,54 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
     return launch_bwd<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
                                     grad_mask, DIMS, grad_value, grad_loc, grad_spatial_w,
                                     grad_level_w, grad_value_ws, ST_);
+}
+
+
+// ---- reference windows + offsets -> sampling grid ------------------------------------------
+static int grid_dims(int ref_dim, int ref_per_head, int V, int angle_mode, int B, int Lq, int H,
+                     int L, int P, GridDims &d)
+{
+    if (B < 0 || Lq < 0 || H <= 0 || L <= 0 || P <= 0 || angle_mode < 0 || angle_mode > 2)
+        return 0;
+    if (V != (angle_mode == 1 ? 5 : 4) || ref_dim < (angle_mode ? 5 : 4)) return 0;
+    d = GridDims{Lq, H, L, P, V, ref_dim, ref_per_head ? 1 : 0, angle_mode};
+    return ((size_t)B * Lq == 0) ? 2 : 1;                       // 2: nothing to do
+}
+
+int boxattn_grid_fwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                         int V, int angle_mode, const float *kernel_idx,
+                         const float *valid_ratios, int B, int Lq, int H, int L, int P,
+                         float *grid, void *stream)
+{
+    GridDims d{};
+    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, d);
+    if (ok == 2) return 0;
+    if (ok != 1 || !ref || !offsets || !kernel_idx || !grid) return (int)hipErrorInvalidValue;
+    const size_t n_pts = (size_t)B * Lq * H * L * P;
+    const size_t blocks = (n_pts + 255) / 256;
+    if (blocks > 0x7fffffffu) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(grid_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       ref, offsets, kernel_idx, valid_ratios, d, n_pts, grid);
+    return finish();
+}
+
+int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                         int V, int angle_mode, const float *kernel_idx,
+                         const float *valid_ratios, const float *grad_grid, int B, int Lq, int H,
+                         int L, int P, float *grad_offsets, float *grad_ref_rows, void *stream)
+{
+    GridDims d{};
+    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, d);
+    if (ok == 2) return 0;
+    if (ok != 1 || !ref || !offsets || !kernel_idx || !grad_grid || !grad_offsets)
+        return (int)hipErrorInvalidValue;
+    const size_t n_rows = (size_t)B * Lq * H * L;
+    const size_t blocks = (n_rows * 4 + 255) / 256;
+    if (blocks > 0x7fffffffu) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(grid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       ref, offsets, kernel_idx, valid_ratios, grad_grid, d, n_rows, grad_offsets,
+                       grad_ref_rows);
+    return finish();
 }
 
 }  // extern "C"

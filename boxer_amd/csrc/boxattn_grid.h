@@ -1,0 +1,141 @@
+// Reference windows + predicted offsets -> sampling grid, and its backward: everything of the
+// modules' `_where_to_attend` after the box-offset projection (reference
+// e2edet/module/box_attention.py:63-81, 196-214, 304-338) as one kernel each way instead of
+// ~15 elementwise passes (4 of them over the (B,Lq,H,L,P,2) grid).
+//
+//   ref     (B, Lq, D) or (B, Lq, H, D)   (cx, cy, w, h[, angle, ...]), D >= 4
+//   offsets (B, Lq, H, L, V)              V = 4, or 5 with a learned rotation
+//   kidx    (P, 2)                        the module's `kernel_indices` buffer
+//   vr      (B, L, 2) or null             `v_valid_ratios` (B,1,1,L,1,2)
+//   box     = ref[:4] + offsets[:4] / 8 * (w, h, w, h)_ref
+//   theta   = none (angle_mode 0) | (ref[4] + offsets[4] / 16) * 2 pi (1) | ref[4] (2)
+//   grid[n, p] = (c + R(theta) (kidx_p * relu(size))) * vr        n = (b, q, h, l)
+//
+// Same operation order as the torch code (no FMA contraction), so without rotation the grid
+// is bit-identical; with rotation the device sin / cos differ from torch's by an ulp.
+#pragma once
+#include "boxattn_device.h"
+
+namespace boxattn {
+
+struct GridDims {
+    int Lq, H, L, P, V;
+    int ref_dim, ref_per_head, angle_mode;
+};
+
+struct GridBox { float cx, cy, w, h, sn, cs, vx, vy, rw, rh; };
+
+__device__ __forceinline__ GridBox grid_box(const float *__restrict__ ref,
+                                            const float *__restrict__ offsets,
+                                            const float *__restrict__ vr, const GridDims &d,
+                                            size_t n)
+{
+#pragma clang fp contract(off)
+    const int l = (int)(n % (unsigned)d.L);
+    const size_t bqh = n / (unsigned)d.L;
+    const int h = (int)(bqh % (unsigned)d.H);
+    const size_t bq = bqh / (unsigned)d.H;
+    const size_t b = bq / (unsigned)d.Lq;
+    const float *r = ref + (d.ref_per_head ? bqh : bq) * (unsigned)d.ref_dim;
+    const float *o = offsets + n * (unsigned)d.V;
+    GridBox g;
+    g.rw = r[2];
+    g.rh = r[3];
+    g.cx = r[0] + o[0] / 8.f * g.rw;
+    g.cy = r[1] + o[1] / 8.f * g.rh;
+    g.w = g.rw + o[2] / 8.f * g.rw;
+    g.h = g.rh + o[3] / 8.f * g.rh;
+    g.sn = 0.f;
+    g.cs = 1.f;
+    if (d.angle_mode == 1) sincosf((r[4] + o[4] / 16.f) * 2.f * 3.14159265358979323846f, &g.sn, &g.cs);
+    else if (d.angle_mode == 2) sincosf(r[4], &g.sn, &g.cs);
+    g.vx = vr ? vr[(b * d.L + l) * 2] : 1.f;
+    g.vy = vr ? vr[(b * d.L + l) * 2 + 1] : 1.f;
+    (void)h;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__ ref,
+                                                       const float *__restrict__ offsets,
+                                                       const float *__restrict__ kidx,
+                                                       const float *__restrict__ vr, GridDims d,
+                                                       size_t n_pts, float *__restrict__ grid)
+{
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (row n, point p)
+    if (i >= n_pts) return;
+    const size_t n = i / (unsigned)d.P;
+    const int p = (int)(i - n * (unsigned)d.P);
+    const GridBox g = grid_box(ref, offsets, vr, d, n);
+    const float lx = kidx[2 * p] * fmaxf(g.w, 0.f), ly = kidx[2 * p + 1] * fmaxf(g.h, 0.f);
+    float gx, gy;
+    if (d.angle_mode) {
+        gx = g.cx + (lx * g.cs - ly * g.sn);
+        gy = g.cy + (lx * g.sn + ly * g.cs);
+    } else {
+        gx = g.cx + lx;
+        gy = g.cy + ly;
+    }
+    if (vr) {
+        gx = gx * g.vx;
+        gy = gy * g.vy;
+    }
+    reinterpret_cast<float2 *>(grid)[i] = make_float2(gx, gy);
+}
+
+// grad_offsets (N, V) and, if asked for, the per-row gradient of the reference window
+// grad_ref_rows (N, 5) = d/d(cx, cy, w, h, angle)_ref (summed over levels / heads by the
+// caller): four lanes per row (a DPP quad), points strided over them, quad sum at the end.
+__global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__ ref,
+                                                       const float *__restrict__ offsets,
+                                                       const float *__restrict__ kidx,
+                                                       const float *__restrict__ vr,
+                                                       const float *__restrict__ grad_grid,
+                                                       GridDims d, size_t n_rows,
+                                                       float *__restrict__ grad_offsets,
+                                                       float *__restrict__ grad_ref_rows)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = t / 4;
+    const int j = (int)(t % 4);
+    const bool live = n < n_rows;
+    if (!live) n = n_rows - 1;                                  // keep the quad together
+    const GridBox g = grid_box(ref, offsets, vr, d, n);
+    const float2 *gg = reinterpret_cast<const float2 *>(grad_grid) + n * (unsigned)d.P;
+    float gcx = 0.f, gcy = 0.f, gw = 0.f, gh = 0.f, gt = 0.f;
+    const float wr = fmaxf(g.w, 0.f), hr = fmaxf(g.h, 0.f);
+    for (int p = j; p < d.P; p += 4) {
+        const float2 q = gg[p];
+        const float gx = q.x * g.vx, gy = q.y * g.vy;           // d / d (unscaled grid)
+        const float kx = kidx[2 * p], ky = kidx[2 * p + 1];
+        gcx += gx;
+        gcy += gy;
+        gw += kx * (gx * g.cs + gy * g.sn);                     // d / d relu(w)
+        gh += ky * (gy * g.cs - gx * g.sn);                     // d / d relu(h)
+        const float lx = kx * wr, ly = ky * hr;
+        gt += gx * (-lx * g.sn - ly * g.cs) + gy * (lx * g.cs - ly * g.sn);
+    }
+    gcx = group_sum<4>(gcx); gcy = group_sum<4>(gcy);
+    gw = group_sum<4>(gw); gh = group_sum<4>(gh); gt = group_sum<4>(gt);
+    if (!(live && j == 0)) return;
+    gw = g.w > 0.f ? gw : 0.f;                                  // relu'
+    gh = g.h > 0.f ? gh : 0.f;
+    const float *o = offsets + n * (unsigned)d.V;
+    float *go = grad_offsets + n * (unsigned)d.V;
+    go[0] = gcx * g.rw / 8.f;
+    go[1] = gcy * g.rh / 8.f;
+    go[2] = gw * g.rw / 8.f;
+    go[3] = gh * g.rh / 8.f;
+    const float two_pi = 2.f * 3.14159265358979323846f;
+    if (d.V == 5) go[4] = d.angle_mode == 1 ? gt * two_pi / 16.f : 0.f;
+    if (grad_ref_rows) {
+        float *gr = grad_ref_rows + n * 5;
+        gr[0] = gcx;
+        gr[1] = gcy;
+        gr[2] = gcx * o[0] / 8.f + gw * (1.f + o[2] / 8.f);
+        gr[3] = gcy * o[1] / 8.f + gh * (1.f + o[3] / 8.f);
+        gr[4] = d.angle_mode == 1 ? gt * two_pi : (d.angle_mode == 2 ? gt : 0.f);
+    }
+}
+
+}  // namespace boxattn

@@ -148,3 +148,41 @@ class InstanceAttnBF16Function(Function):
         grads = _inst_backward(ctx, grad_output.to(torch.bfloat16),
                                grad_mask_output.to(torch.bfloat16))
         return (grads[0].to(ctx.value_dtype),) + grads[1:]
+
+
+class BoxGridFunction(Function):
+    """(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode) -> sampling grid
+    (B,Lq,H,L,P,2): everything of the modules' ``_where_to_attend`` after the offset projection
+    in one kernel each way (``module.fused_grid = True``; see ``ops.box_grid_forward``).
+    Gradients for ``offsets`` and, if it requires one, ``ref_windows``."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, ref_windows, offsets, kernel_indices, valid_ratios, angle_mode):
+        ref_windows = ref_windows.contiguous()
+        offsets = offsets.contiguous()
+        kernel_indices = kernel_indices.contiguous()
+        if valid_ratios is not None:
+            valid_ratios = valid_ratios.contiguous()
+        ctx.save_for_backward(ref_windows, offsets, kernel_indices, valid_ratios)
+        ctx.angle_mode = angle_mode
+        return ops.box_grid_forward(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode)
+
+    @staticmethod
+    @once_differentiable
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_grid):
+        ref_windows, offsets, kernel_indices, valid_ratios = ctx.saved_tensors
+        need_ref = ctx.needs_input_grad[0]
+        grad_offsets, rows = ops.box_grid_backward(
+            ref_windows, offsets, kernel_indices, valid_ratios, ctx.angle_mode,
+            grad_grid.contiguous().float(), need_ref_grad=need_ref)
+        grad_ref = None
+        if need_ref:
+            # rows: d/d(cx, cy, w, h, angle)_ref per (head, level); the windows are shared by
+            # the levels and, unless given per head, by the heads
+            rows = rows.sum(dim=3) if ref_windows.dim() == 4 else rows.sum(dim=(2, 3))
+            grad_ref = torch.zeros_like(ref_windows)
+            n = min(5, ref_windows.size(-1))
+            grad_ref[..., :n] = rows[..., :n]
+        return grad_ref, grad_offsets, None, None, None

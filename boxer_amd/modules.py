@@ -20,7 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functions import (BoxAttnBF16Function, BoxAttnFunction, InstanceAttnBF16Function,
+from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
+                        InstanceAttnBF16Function,
                         InstanceAttnFunction)
 
 
@@ -47,6 +48,8 @@ class _BoxAttentionBase(nn.Module):
         self.head_dim = d_model // num_head
         self.kernel_size = kernel_size
         self.native_bf16 = False
+        # opt-in: box -> grid expansion in one HIP kernel each way (BoxGridFunction)
+        self.fused_grid = False
 
         self.linear_box_weight = nn.Parameter(torch.zeros(num_level * num_head * box_vars, d_model))
         self.linear_box_bias = nn.Parameter(torch.zeros(num_head * num_level * box_vars))
@@ -99,6 +102,16 @@ class _BoxAttentionBase(nn.Module):
     def _box_function(self):
         return BoxAttnBF16Function if self.native_bf16 else BoxAttnFunction
 
+    def _use_fused_grid(self, query, v_valid_ratios):
+        """The fused kernel covers the reference's call shapes: CUDA tensors and
+        ``v_valid_ratios`` None or (B,1,1,L,1,2) (box_transformer.py:118-138)."""
+        if not (self.fused_grid and query.is_cuda) or query.dtype == torch.float64:
+            return False                      # (the kernel computes in float32)
+        return v_valid_ratios is None or (
+            v_valid_ratios.dim() == 6
+            and tuple(v_valid_ratios.shape[1:]) == (1, 1, self.num_level, 1, 2)
+            and v_valid_ratios.size(0) == query.size(0))
+
 
 class BoxAttention(_BoxAttentionBase):
     def __init__(self, d_model, num_level, num_head, kernel_size=2):
@@ -108,6 +121,9 @@ class BoxAttention(_BoxAttentionBase):
 
     def _where_to_attend(self, query, v_valid_ratios, ref_windows):
         offset_boxes = self._box_offsets(query, ref_windows, 4)
+        if self._use_fused_grid(query, v_valid_ratios):
+            return BoxGridFunction.apply(ref_windows, offset_boxes, self.kernel_indices,
+                                         v_valid_ratios, 0)
         center, size = self._decode_boxes(self._per_head_level(ref_windows), offset_boxes)
         grid = center + self.kernel_indices * torch.relu(size)
         if v_valid_ratios is not None:
@@ -143,6 +159,9 @@ class Box3dAttention(BoxAttention):
     def _where_to_attend(self, query, v_valid_ratios, ref_windows):
         b, l = ref_windows.shape[:2]
         offsets = self._box_offsets(query, ref_windows, self.num_variable)
+        if self._use_fused_grid(query, v_valid_ratios):
+            return BoxGridFunction.apply(ref_windows, offsets, self.kernel_indices,
+                                         v_valid_ratios, 1 if self.with_rotation else 2)
         ref = self._per_head_level(ref_windows)       # (cx,cy,w,h,angle[,vx,vy])
         ref_boxes, ref_angles = ref[..., :4], ref[..., 4:5]
         if self.with_rotation:

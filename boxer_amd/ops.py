@@ -264,3 +264,75 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
         _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
                                  dims, args, plan)
     return [grad_value, grad_loc, grad_sw, grad_lw]
+
+
+# ---------------------------------------------------------------------------------------
+# reference windows + box offsets -> sampling grid (opt-in, beyond the reference's native
+# module; SURVEY.md 8(f) N1, first step)
+# ---------------------------------------------------------------------------------------
+def _grid_args(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode):
+    _check(ref_windows, "ref_windows")
+    _check(offsets, "offsets")
+    _check(kernel_indices, "kernel_indices")
+    for t in (ref_windows, offsets, kernel_indices):
+        if t.dtype != torch.float32:
+            raise RuntimeError("box_grid: float32 tensors expected")
+    if offsets.dim() != 5 or ref_windows.dim() not in (3, 4):
+        raise RuntimeError("expected offsets (B,Lq,H,L,V) and ref_windows (B,Lq,D) or (B,Lq,H,D)")
+    if kernel_indices.dim() != 2 or kernel_indices.size(1) != 2:
+        raise RuntimeError("expected kernel_indices (P,2)")
+    B, Lq, H, L, V = offsets.shape
+    per_head = ref_windows.dim() == 4
+    D = ref_windows.size(-1)
+    if tuple(ref_windows.shape[:2]) != (B, Lq) or (per_head and ref_windows.size(2) != H):
+        raise RuntimeError("ref_windows do not match offsets")
+    if angle_mode not in (0, 1, 2) or V != (5 if angle_mode == 1 else 4) or \
+            D < (5 if angle_mode else 4):
+        raise RuntimeError("box_grid: offsets / ref_windows do not fit angle_mode %r" % angle_mode)
+    if valid_ratios is not None:
+        _check(valid_ratios, "valid_ratios")
+        if valid_ratios.dtype != torch.float32 or valid_ratios.numel() != B * L * 2:
+            raise RuntimeError("expected valid_ratios with B*L*2 float32 elements")
+    return (B, Lq, H, L, kernel_indices.size(0)), (D, int(per_head), V, angle_mode)
+
+
+def _grid_call(name, anchor, *args):
+    fn = getattr(_lib.load(), name)
+    with torch.cuda.device(anchor.device):
+        stream = torch.cuda.current_stream(anchor.device).cuda_stream
+        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream)
+    if rc != 0:
+        raise RuntimeError("%s failed with hipError %d" % (name, rc))
+
+
+def box_grid_forward(ref_windows, offsets, kernel_indices, valid_ratios=None, angle_mode=0):
+    """Everything of the modules' ``_where_to_attend`` after the offset projection
+    (box_attention.py:63-81, 304-338) in one kernel:
+    ``box = ref[:4] + offsets[:4]/8 * (w,h,w,h)_ref``; rotation ``theta`` none (angle_mode 0),
+    ``(ref[4] + offsets[4]/16) * 2 pi`` (1) or ``ref[4]`` (2);
+    ``grid = (c + R(theta)(kernel_indices * relu(size))) * valid_ratios`` -> (B,Lq,H,L,P,2)."""
+    dims, (D, per_head, V, mode) = _grid_args(ref_windows, offsets, kernel_indices, valid_ratios,
+                                              angle_mode)
+    B, Lq, H, L, P = dims
+    grid = torch.empty((B, Lq, H, L, P, 2), dtype=torch.float32, device=offsets.device)
+    _grid_call("boxattn_grid_fwd_f32", offsets, ref_windows, D, per_head, offsets, V, mode,
+               kernel_indices, valid_ratios if valid_ratios is not None else 0, *dims, grid)
+    return grid
+
+
+def box_grid_backward(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode, grad_grid,
+                      need_ref_grad=False):
+    """-> (grad_offsets (B,Lq,H,L,V), grad_ref_rows (B,Lq,H,L,5) or None)."""
+    dims, (D, per_head, V, mode) = _grid_args(ref_windows, offsets, kernel_indices, valid_ratios,
+                                              angle_mode)
+    B, Lq, H, L, P = dims
+    _check(grad_grid, "grad_grid")
+    if grad_grid.dtype != torch.float32 or grad_grid.numel() != B * Lq * H * L * P * 2:
+        raise RuntimeError("expected grad_grid (B,Lq,H,L,P,2) float32")
+    grad_offsets = torch.empty_like(offsets)
+    grad_rows = torch.empty((B, Lq, H, L, 5), dtype=torch.float32, device=offsets.device) \
+        if need_ref_grad else None
+    _grid_call("boxattn_grid_bwd_f32", offsets, ref_windows, D, per_head, offsets, V, mode,
+               kernel_indices, valid_ratios if valid_ratios is not None else 0, grad_grid, *dims,
+               grad_offsets, grad_rows if grad_rows is not None else 0)
+    return grad_offsets, grad_rows

@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 4
+#define BOXATTN_ABI_VERSION 5
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -159,6 +159,34 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
         void *stream);
+
+/*
+ * ---- reference windows + box offsets -> sampling grid (opt-in; SURVEY.md 8(f) N1, first step) --
+ * Everything of the modules' `_where_to_attend` after the box-offset projection
+ * (e2edet/module/box_attention.py:63-81 BoxAttention / InstanceAttention, :304-338
+ * Box3dAttention) as one kernel each way:
+ *     box   = ref[:4] + offsets[:4] / 8 * (w, h, w, h)_ref
+ *     theta = none (angle_mode 0) | (ref[4] + offsets[4] / 16) * 2 pi (1) | ref[4] (2)
+ *     grid[b,q,h,l,p,:] = (c + R(theta) (kernel_idx[p] * relu(size))) * valid_ratios[b,l,:]
+ *   ref          (B, Lq, ref_dim) or, ref_per_head != 0, (B, Lq, H, ref_dim); float32,
+ *                ref_dim >= 4 (>= 5 with an angle); columns beyond the angle are ignored
+ *   offsets      (B, Lq, H, L, V) float32, V = 4, or 5 for angle_mode 1
+ *   kernel_idx   (P, 2) float32, the module's `kernel_indices` buffer
+ *   valid_ratios (B, L, 2) float32 or NULL (`v_valid_ratios`, (B,1,1,L,1,2) in the reference)
+ *   grid / grad_grid (B, Lq, H, L, P, 2) float32 -- the `sampling_locations` of the operator
+ *   grad_offsets (B, Lq, H, L, V) float32, fully written
+ *   grad_ref_rows (B, Lq, H, L, 5) float32 or NULL: per-(head, level) gradient of
+ *                (cx, cy, w, h, angle)_ref; the caller sums it over L (and H) if it needs
+ *                the gradient of the reference windows
+ */
+int boxattn_grid_fwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                         int V, int angle_mode, const float *kernel_idx,
+                         const float *valid_ratios, int B, int Lq, int H, int L, int P,
+                         float *grid, void *stream);
+int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                         int V, int angle_mode, const float *kernel_idx,
+                         const float *valid_ratios, const float *grad_grid, int B, int Lq, int H,
+                         int L, int P, float *grad_offsets, float *grad_ref_rows, void *stream);
 
 /*
  * ---- training forward: forward + backward plan ----------------------------------------------

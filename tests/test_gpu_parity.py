@@ -7,6 +7,8 @@ C ABI (boxer_amd.ops -> libboxattn_hip.so), against
 Tolerances (BASELINE.json north_star): fp64 1e-10, fp32 1e-4, bf16 1e-2 -- absolute on
 O(1) data, scaled by the magnitude of the expected tensor when that exceeds 1.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -409,6 +411,110 @@ def test_modules_match_reference_goldens():
                      with_rotation=False, kernel_size=3)
     out, _ = m(*args(g, False, False))
     close(out, g["out"], torch.float64, "Box3dAttention(fixed) out")
+
+
+# ------------------------------------------------------------------ box -> grid (opt-in)
+def _torch_grid(ref, off, kidx, vr, angle_mode):
+    """The reference modules' _where_to_attend after the offset projection
+    (box_attention.py:63-81, 304-338)."""
+    r = ref[:, :, None, None] if ref.dim() == 3 else ref[:, :, :, None]
+    wh = r[..., 2:4]
+    boxes = r[..., :4] + off[..., :4] / 8 * torch.cat([wh, wh], dim=-1)
+    boxes = boxes.unsqueeze(-2)
+    c, size = boxes[..., :2], boxes[..., 2:]
+    local = kidx * torch.relu(size)
+    if angle_mode:
+        ang = (r[..., 4:5] + off[..., 4:5] / 16) * 2 * math.pi if angle_mode == 1 \
+            else r[..., 4:5].expand(off.shape[:4] + (1,))
+        cos, sin = torch.cos(ang), torch.sin(ang)
+        lx, ly = local[..., 0], local[..., 1]
+        local = torch.stack([lx * cos - ly * sin, lx * sin + ly * cos], dim=-1)
+    grid = c + local
+    return grid * vr if vr is not None else grid
+
+
+@pytest.mark.parametrize("angle_mode", [0, 1, 2])
+@pytest.mark.parametrize("P", [1, 4, 9, 196])
+@pytest.mark.parametrize("per_head,with_ratio", [(False, False), (False, True), (True, True)])
+def test_box_grid_op_matches_torch(angle_mode, P, per_head, with_ratio):
+    from boxer_amd import BoxGridFunction
+    gen = torch.Generator(device="cuda").manual_seed(100 + 10 * angle_mode + P)
+    B, Lq, H, L = 2, 37, 3, 2
+    V, D = (5 if angle_mode == 1 else 4), (7 if angle_mode else 4)
+    ref = torch.rand((B, Lq, H, D) if per_head else (B, Lq, D), device="cuda", generator=gen)
+    off = torch.randn(B, Lq, H, L, V, device="cuda", generator=gen) * 4    # some sizes <= 0
+    k = int(round(P ** 0.5))
+    kidx = (torch.rand(P, 2, device="cuda", generator=gen) - 0.5) if k * k != P else \
+        torch.stack(torch.meshgrid(torch.linspace(-0.5, 0.5, k, device="cuda"),
+                                   torch.linspace(-0.5, 0.5, k, device="cuda"),
+                                   indexing="ij")[::-1], -1).reshape(P, 2).contiguous()
+    vr = (0.5 + 0.5 * torch.rand(B, 1, 1, L, 1, 2, device="cuda", generator=gen)) \
+        if with_ratio else None
+    w = torch.randn(B, Lq, H, L, P, 2, device="cuda", generator=gen)
+
+    r1, o1 = ref.clone().requires_grad_(), off.clone().requires_grad_()
+    want = _torch_grid(r1, o1, kidx, vr, angle_mode)
+    (want * w).sum().backward()
+    r2, o2 = ref.clone().requires_grad_(), off.clone().requires_grad_()
+    got = BoxGridFunction.apply(r2, o2, kidx, vr, angle_mode)
+    (got * w).sum().backward()
+    assert got.shape == want.shape
+    assert (1 + off[..., 2:4] / 8 <= 0).any(), "the case should contain collapsed boxes (relu)"
+    if angle_mode == 0:
+        assert torch.equal(got, want.detach()), "grid is not bit-identical to the torch ops"
+    else:
+        torch.testing.assert_close(got, want.detach(), rtol=0, atol=3e-6)
+    tol = 2e-5 * max(1.0, P ** 0.5)
+    torch.testing.assert_close(o2.grad, o1.grad, rtol=1e-4, atol=tol)
+    torch.testing.assert_close(r2.grad, r1.grad, rtol=1e-4, atol=tol * (L * (1 if per_head else H)))
+    # offsets only: no reference-window gradient is computed or returned
+    o3 = off.clone().requires_grad_()
+    got3 = BoxGridFunction.apply(ref, o3, kidx, vr, angle_mode)
+    (got3 * w).sum().backward()
+    assert torch.equal(o3.grad, o2.grad)
+
+
+def test_modules_with_fused_grid():
+    """module.fused_grid = True changes neither outputs nor parameter gradients."""
+    from boxer_amd import Box3dAttention, BoxAttention, InstanceAttention
+    torch.manual_seed(5)
+    d, nl, nh = 64, 2, 4
+    shapes = torch.tensor([[9, 7], [5, 4]], device="cuda")
+    lsi = torch.tensor([0, 63], device="cuda")
+    S, B, Lq = 83, 2, 11
+    value = torch.randn(B, S, d, device="cuda")
+    ratios = 0.6 + 0.4 * torch.rand(B, 1, 1, nl, 1, 2, device="cuda")
+    cases = [
+        (BoxAttention(d, nl, nh, 2), torch.rand(B, Lq, 4, device="cuda"), ratios),
+        (BoxAttention(d, nl, nh, 3), torch.rand(B, Lq, nh, 4, device="cuda"), None),
+        (InstanceAttention(d, nl, nh, 4), torch.rand(B, Lq, 4, device="cuda"), ratios),
+        (Box3dAttention(d, nl, nh, True, 2), torch.rand(B, Lq, 7, device="cuda"), ratios),
+        (Box3dAttention(d, nl, nh, False, 2), torch.rand(B, Lq, nh, 5, device="cuda"), None),
+    ]
+    for m, ref, vr in cases:
+        m = m.cuda()
+        with torch.no_grad():                                # make the box branch non-trivial
+            m.linear_box_weight.normal_(0, 0.05)
+            m.linear_attn_weight.normal_(0, 0.05)
+        if isinstance(m, InstanceAttention):
+            m.inferencing = False
+        query = torch.randn(B, Lq, d, device="cuda")
+        res = []
+        for fused in (False, True):
+            m.fused_grid = fused
+            m.zero_grad()
+            q = query.clone().requires_grad_()
+            out = m(q, value, shapes, None, lsi, vr, ref)
+            loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device="cuda").view_as(o)).sum()
+                       for o in out if isinstance(o, torch.Tensor))
+            loss.backward()
+            res.append((out[0].detach(), q.grad.clone(), m.linear_box_weight.grad.clone(),
+                        m.linear_box_bias.grad.clone()))
+        name = type(m).__name__
+        for a, b_, what in zip(res[0], res[1], ("out", "grad_query", "grad_box_w", "grad_box_b")):
+            scale = max(1.0, float(a.abs().max()))
+            torch.testing.assert_close(b_, a, rtol=0, atol=2e-4 * scale,
+                                       msg=lambda s_, n=name, w=what: "%s %s: %s" % (n, w, s_))
 
 
 # ------------------------------------------------------------------ full-size properties
