@@ -1,3 +1,4 @@
-timeout 900 python -m pytest tests -m gpu -x -q -k "grid or modules" 2>&1 | tail -5
-python tools/gpu_grid_bench.py 2 2>&1 | tail -3
-python tools/gpu_grid_bench.py 16 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_train_harness.py -m gpu -x -q 2>&1 | tail -5
+for a in "--dtype fp32" "--dtype fp32 --fused-grid" "--dtype bf16" "--dtype bf16 --fused-grid"; do
+timeout 600 python bench_train.py --steps 10 --warmup 3 $a 2>&1 | tail -1
+done
