@@ -513,10 +513,10 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     float *partials = (float *)(ws + w.partials);
-    // grad_loc / grad_weight (query-major gathers) do not depend on the binning: run them on the
-    // library's helper stream, concurrently with the bin passes and the accumulate kernel, which
-    // is latency-bound at ~13 waves per CU and leaves issue slots free.  Fork/join with events,
-    // so the caller still sees one in-order stream (also valid under stream capture).
+    // grad_loc / grad_weight (query-major gathers) do not depend on the binning: they are launched
+    // on the library's helper stream, next to the bin passes and the accumulate kernel.  Fork/join
+    // with events, so the caller still sees one in-order stream (also valid under stream capture).
+    // (Measured gain of the overlap: none to a few percent -- DESIGN.md 4.3.)
     SideStream side(st, d.n_qh() * d.L * d.P >= kSideStreamMinPoints);
     if (!plan_ready) launch_binning(loc, d, plan, w, ws, st);
     {
@@ -546,16 +546,16 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         }
     }
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
-    // real count lives on the device, surplus workgroups exit at once).  ~13 fit per CU (LDS),
-    // the hardware dispatcher hands out the rest as waves retire -- dynamic load balancing
-    // without a work-queue atomic (167 -> 146 us against 208 persistent waves per slice).  The
+    // real count lives on the device, surplus workgroups exit at once); the hardware dispatcher
+    // hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
+    // persistent-waves version with a software queue was 15 % slower).  The
     // kernel maps workgroups to (slice, worker) itself (XCD affinity), hence the 8-aligned grid.
     const int ns8 = (ns + 7) / 8 * 8;
     const int wg_per_slice = std::max(1, plan.item_cap);
     {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
-        // two records per lane and round pay off for bf16 box attention (fewer rounds: 141 ->
-        // 126 us); fp32 and the instance flavour run out of registers / LDS with it
+        // records per lane and round: one is best for every flavour now that the bin passes
+        // interleave the queries (two were better for bf16 box attention before that)
 #ifndef BOXATTN_TUNE_RPL_BF16
 #define BOXATTN_TUNE_RPL_BF16 1
 #endif
