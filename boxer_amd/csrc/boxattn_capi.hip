@@ -215,14 +215,32 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
             // instance attention with few queries and many points: split the points of a pair
             // over several workgroups (fp32 only: partial outs are combined with atomics)
+            // (variant 5 = A/B switch: keep the split instead of the one-wave-per-pair kernel)
+            const bool wide = INST && gen2 && g_variant != 5 && blocks < 1024 &&
+                              d.P >= 2 * (kWave / G);
             int fsplit = 1;
-            if (INST && gen2 && std::is_same<ST, float>::value)
+            if (INST && gen2 && !wide && std::is_same<ST, float>::value)
                 fsplit = point_split(blocks, (d.P + G - 1) / G);
             if (fsplit > 1) {
                 hipError_t e = hipMemsetAsync(out, 0, n_qh * d.C * sizeof(ST), st);
                 if (e != hipSuccess) return (int)e;
             }
             ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+            // instance attention with few pairs and many points: one wave per pair, the points
+            // spread over the lane groups (any storage type; replaces the fp32-only atomic
+            // split when it gives more waves)
+            if constexpr (INST) {
+                if (wide) {
+                    const int wblocks = ceil_div_sz(n_qh, 4);
+#define BOXATTN_FWD_WIDE(GG, VV)                                                              \
+    hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(wblocks), dim3(256), 0, st,   \
+                       value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out,    \
+                       mask, ix, (unsigned)vbytes);
+                    BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD_WIDE);
+#undef BOXATTN_FWD_WIDE
+                    return finish();
+                }
+            }
             if (gen2) {
 #define BOXATTN_FWD2(GG, VV)                                                                  \
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
@@ -586,7 +604,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     if (!d.valid()) return (int)hipErrorInvalidValue;
     BinPlan plan;
     const size_t nv = d.n_value();
-    bool binned = (g_variant == 0 || g_variant == 3 || g_variant == 4) && workspace && nv && d.n_qh() &&
+    bool binned = (g_variant == 0 || g_variant >= 3) && workspace && nv && d.n_qh() &&
                   make_plan(d, shapes_host, lsi_host, plan) &&
                   fast_ok<ST>(d, value, loc, grad_out,
                               INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
@@ -639,7 +657,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
 {
     if (plan_built) *plan_built = 0;
     BinPlan plan;
-    bool ok = (g_variant == 0 || g_variant == 3 || g_variant == 4) && workspace && d.valid() &&
+    bool ok = (g_variant == 0 || g_variant >= 3) && workspace && d.valid() &&
               d.n_value() && d.n_qh() && make_plan(d, shapes_host, lsi_host, plan) &&
               aligned(workspace, 256) && aligned(loc, 8);
     WsLayout w{};

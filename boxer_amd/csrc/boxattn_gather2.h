@@ -429,6 +429,122 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// forward, instance attention with FEW (query, head) pairs and many points (the mask decoder:
+// 300 queries x 14x14 points): one WAVE per pair.  The 64 / G lane groups take different points
+// of the pair; inside a group lane t does the geometry of level l0 + t of the group's point and
+// the G lanes then walk these levels together (same step A / step B split as fwd2_kernel).  A
+// group owns mask_out[b,q,p,m,:] of its points; `out` is summed over the groups with
+// cross-lane adds at the end -- no atomics, no zero-fill, any storage type.
+// ---------------------------------------------------------------------------------------
+template <int G> __device__ __forceinline__ unsigned group_bcast(unsigned v, int t, int lane)
+{
+    if constexpr (G == 4) return quad_bcast(v, t);
+    else return (unsigned)__shfl((int)v, (lane & ~(G - 1)) + t, kWave);
+}
+
+template <typename ST, int G, int VEC>
+__global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
+    const ST *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc,
+    const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
+    int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes)
+{
+    constexpr int C = VEC * G, NG = kWave / G;
+    typedef Row<ST, VEC> RowT;
+    constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;
+    constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);
+    __shared__ LevelTable lv;
+    load_levels(lv, shapes, lsi, L);
+
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const unsigned qh = blockIdx.x * (blockDim.x / kWave) + wv;      // one pair per wave
+    if (qh >= ix.n_qh) return;                                          // wave-uniform
+    const int slot = lane % G, grp = lane / G;
+    unsigned bq, hu, b, qu;
+    divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
+    divmod_magic(bq, (unsigned)Lq, ix.magic_lq, b, qu);
+    const int h = (int)hu;
+    const size_t HC = (size_t)H * C;
+    const size_t pt0 = (size_t)qh * L * P;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(value), 0, value_bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)(slot * RowT::kLaneBytes);
+    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    ST *mk = mask + (size_t)bq * P * HC + (size_t)h * C + slot * LCH;
+
+    f32x2 acc[VEC / 2];
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) acc[i] = f32x2{0.f, 0.f};
+
+    for (int p0 = 0; p0 < P; p0 += NG) {                              // wave-uniform trip count
+        const int p = p0 + grp;
+        const bool have_p = p < P;
+        f32x2 macc[VEC / 2];
+#pragma unroll
+        for (int i = 0; i < VEC / 2; ++i) macc[i] = f32x2{0.f, 0.f};
+        for (int l0 = 0; l0 < L; l0 += G) {
+            // ---- step A: lane t of the group -> level l0 + t of point p
+            const int l = l0 + slot;
+            const bool have = have_p && l < L;
+            const int lc = min(l, L - 1);
+            const size_t i = pt0 + (size_t)lc * P + (have_p ? p : P - 1);
+            const float2 xy = loc2[i];
+            const float as = have ? w_sp[i] : 0.f;
+            const float al = have ? w_lv[i] : 0.f;
+            const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[lc], lv.w[lc]);
+            const u32x4_t my_off =
+                corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[lc], H, h, C, have);
+            const u32x4_t my_wt = as_u32x4(s.hh * s.hw, s.hh * s.lw, s.lh * s.hw, s.lh * s.lw);
+            // ---- step B: the G lanes walk the G levels together
+            u32x4_t off[G], wt[G];
+            unsigned aas[G], aal[G];
+            RowT v[G][4];
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                off[t] = u32x4_t{group_bcast<G>(my_off.x, t, lane), group_bcast<G>(my_off.y, t, lane),
+                                 group_bcast<G>(my_off.z, t, lane), group_bcast<G>(my_off.w, t, lane)};
+                wt[t] = u32x4_t{group_bcast<G>(my_wt.x, t, lane), group_bcast<G>(my_wt.y, t, lane),
+                                group_bcast<G>(my_wt.z, t, lane), group_bcast<G>(my_wt.w, t, lane)};
+                aas[t] = group_bcast<G>(__float_as_uint(as), t, lane);
+                aal[t] = group_bcast<G>(__float_as_uint(al), t, lane);
+                row_load<ST, VEC, PSB>(rs, off[t].x + lane_off, v[t][0]);
+                row_load<ST, VEC, PSB>(rs, off[t].y + lane_off, v[t][1]);
+                row_load<ST, VEC, PSB>(rs, off[t].z + lane_off, v[t][2]);
+                row_load<ST, VEC, PSB>(rs, off[t].w + lane_off, v[t][3]);
+            }
+            loads_issued();
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                f32x2 val[VEC / 2];
+#pragma unroll
+                for (int k = 0; k < VEC / 2; ++k) val[k] = f32x2{0.f, 0.f};
+                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].x), v[t][0]);
+                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].y), v[t][1]);
+                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].z), v[t][2]);
+                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].w), v[t][3]);
+                const float a_s = __uint_as_float(aas[t]), a_l = __uint_as_float(aal[t]);
+                const f32x2 as2 = {a_s, a_s}, al2 = {a_l, a_l};
+#pragma unroll
+                for (int k = 0; k < VEC / 2; ++k) {
+                    acc[k] = __builtin_elementwise_fma(val[k], as2, acc[k]);
+                    macc[k] = __builtin_elementwise_fma(val[k], al2, macc[k]);
+                }
+            }
+        }
+        if (have_p) row_store<ST, VEC, PSB>(mk + (size_t)p * HC, macc);
+    }
+    // out = sum over the lane groups (lanes with the same channel chunk: stride G)
+#pragma unroll
+    for (int o = G; o < kWave; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < VEC / 2; ++k) {
+            acc[k].x += __shfl_xor(acc[k].x, o, kWave);
+            acc[k].y += __shfl_xor(acc[k].y, o, kWave);
+        }
+    if (grp == 0) row_store<ST, VEC, PSB>(out + (size_t)qh * C + slot * LCH, acc);
+}
+
+// ---------------------------------------------------------------------------------------
 // backward, point gradients only (grad_loc, grad_weight[s]); grad_value is boxattn_binned.h
 // ---------------------------------------------------------------------------------------
 template <typename ST, int G, bool INST, int U, int VEC>

@@ -226,7 +226,10 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
  *       never the binned backward),
  *   3 = binned backward required (error if not eligible),
  *   4 = like 0 but the backward runs on one stream (no helper stream; used for per-kernel
- *       timing).  Returns the previous value.
+ *       timing),
+ *   5 = like 0 but the instance forward with few (query, head) pairs keeps the workgroup
+ *       split of the points instead of the one-wave-per-pair kernel.
+ * Returns the previous value.
  */
 int boxattn_set_variant(int variant);
 

@@ -19,7 +19,7 @@ from oracle import boxattn_oracle as oc
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 1e-2}
-VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3}
+VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3, "split": 5}
 
 
 def dev(a, dtype=None):
@@ -93,7 +93,7 @@ def test_box_golden(name, dtype, variant):
     close(ga, g["grad_attn"], dtype, "grad_attn")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic"])
+@pytest.mark.parametrize("variant", ["auto", "generic", "split"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("name", golden_io.INST)
 def test_instance_golden(name, dtype, variant):
@@ -178,6 +178,10 @@ SEEDED = [
     # per block for chunked work items
     ([(25, 25), (13, 13), (7, 5), (1, 3), (2, 1)], 1, 2, 32, 700, 4),
     ([(13, 21), (5, 4)], 2, 2, 64, 300, 9),                       # 8 channels per lane, G=8 (bf16)
+    # few queries x many points: one wave per (query, head) pair in the instance forward;
+    # 3 and 5 levels do not fill the lane groups evenly
+    ([(11, 9), (6, 5), (3, 2)], 1, 4, 32, 6, 49),
+    ([(11, 9), (6, 5), (3, 2), (2, 2), (1, 1)], 2, 2, 32, 3, 36),
 ]
 
 
