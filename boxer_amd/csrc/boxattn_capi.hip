@@ -217,7 +217,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             // over several workgroups (fp32 only: partial outs are combined with atomics)
             // (variant 5 = A/B switch: keep the split instead of the one-wave-per-pair kernel)
             const bool wide = INST && gen2 && g_variant != 5 && blocks < 1024 &&
-                              d.P >= 2 * (kWave / G);
+                              d.P >= kWave / G;
             int fsplit = 1;
             if (INST && gen2 && !wide && std::is_same<ST, float>::value)
                 fsplit = point_split(blocks, (d.P + G - 1) / G);
