@@ -46,7 +46,9 @@ WORKLOADS = {
     "C3": ([(100, 100), (50, 50), (25, 25), (13, 13)], 300, 16, "instance"),
     "C3p": ([(100, 167), (50, 84), (25, 42), (13, 21)], 300, 196, "instance"),
     "C3pp": ([(100, 167), (50, 84), (25, 42), (13, 21)], 300, 4, "box"),
-    "C5p": ([(234, 234), (117, 117)], "S", 4, "box"),
+    "C5": ([(468, 468)], 1000, 4, "box3d"),                 # literal BEV stress shape, rotated
+    "C5p": ([(234, 234), (117, 117)], "S", 4, "box3d_fixed"),   # BoxeR-3D encoder, 8 fixed angles
+    "C5pp": ([(234, 234), (117, 117)], 300, 4, "box3d"),      # BoxeR-3D decoder, learned rotation
 }
 H_HEADS, C_HEAD, BATCH = 8, 32, 2
 
@@ -76,6 +78,8 @@ def make_inputs(workload, dtype, device, family="model", batch=BATCH, seed=0):
     (the reference's test distribution, tests/box_attn_test.py:57-60) -- worst-case locality.
     """
     levels, lq, P, kind = WORKLOADS[workload]
+    rot = {"box3d": "learned", "box3d_fixed": "fixed"}.get(kind)         # rotated windows (3D)
+    kind = "box" if rot else kind
     L = len(levels)
     S = sum(h * w for h, w in levels)
     Lq = S if lq == "S" else lq
@@ -100,8 +104,16 @@ def make_inputs(workload, dtype, device, family="model", batch=BATCH, seed=0):
         half = (k - 1) / 2.0
         ticks = torch.linspace(-half, half, k, device=device)
         ky, kx = torch.meshgrid(ticks, ticks, indexing="ij")
-        kidx = torch.stack([kx, ky], -1).reshape(-1, 2) / k              # (P,2)
-        loc = boxes[..., None, :2] + kidx * torch.relu(boxes[..., None, 2:])
+        kidx = torch.stack([kx, ky], -1).reshape(-1, 2) / (2 if rot else k)   # (P,2); 3D: /2
+        local = kidx * torch.relu(boxes[..., None, 2:])
+        if rot:      # Box3dAttention: 8 fixed per-head angles (encoder) or a learned one per box
+            ang = (torch.arange(H, device=device, dtype=torch.float32) / H * 2 * math.pi
+                   )[None, None, :, None, None].expand(B, Lq, H, L, 1) if rot == "fixed" else \
+                torch.rand(B, Lq, H, L, 1, device=device, generator=g) * 2 * math.pi
+            lx, ly = local[..., 0], local[..., 1]
+            local = torch.stack([lx * ang.cos() - ly * ang.sin(),
+                                 lx * ang.sin() + ly * ang.cos()], -1)
+        loc = boxes[..., None, :2] + local
         logits = torch.randn(B, Lq, H, L, P, device=device, generator=g)
         attn = torch.softmax(logits.view(B, Lq, H, L * P), -1).view(B, Lq, H, L, P)
         level_w = torch.softmax(logits, dim=3)
@@ -232,6 +244,7 @@ def cpu_baseline(workload, budget_s=20.0):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     levels, lq, P, kind = WORKLOADS[workload]
+    kind = "box" if kind.startswith("box3d") else kind
     # bounded sample: ONE image of the workload (B=1) -- same shapes otherwise
     inp = make_inputs(workload, torch.float32, "cpu", family="model", batch=1, seed=0)
     v = inp["value"].requires_grad_()
