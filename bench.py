@@ -217,14 +217,13 @@ def kernel_profile(step, steps, variant):
     """Average duration of the op's main kernels, measured with HIP events that the library
     records around them on the launch stream (boxattn_profile_*; see include/boxattn.h).
 
-    In the timed region the point-gradient kernel overlaps the binning / accumulate kernels on
-    the library's side stream, which stretches every overlapped kernel; this pass therefore runs
-    the SERIAL schedule (variant 4: same kernels, one stream) so that a kernel's duration is
-    its own."""
+    Same schedule as the timed region (for bf16 that is the one-stream schedule; for fp32 the
+    library overlaps the point-gradient kernel with binning / accumulate on its helper stream,
+    which stretches the overlapped kernels -- `--variant 4` gives their stand-alone times)."""
     from boxer_amd import _lib
     if not hasattr(_lib, "profile_begin"):
         return None
-    _lib.set_variant(4 if variant == 0 else variant)
+    _lib.set_variant(variant)
     for _ in range(3):
         step()
     _lib.profile_begin()
@@ -365,8 +364,8 @@ def main():
         if kern:
             dom = max((k for k in kern if k in b_kernel), key=lambda k: kern[k]["ms"])
             dom_ms, dom_bytes = kern[dom]["ms"], b_kernel[dom]
-            src = ("HIP events around every launch of the kernel (boxattn_profile_*), serial "
-                   "schedule (the timed region overlaps bwd_points with binning/accumulate)")
+            src = ("HIP events around every launch of the kernel (boxattn_profile_*), same "
+                   "schedule as the timed region")
         else:
             dom, dom_ms, dom_bytes = "bwd (whole call)", phases["bwd"], b_bwd
             src = "HIP events around the backward call"

@@ -385,10 +385,12 @@ struct SideStream {
     }
     hipStream_t main_, side_;
     PerDev *p_;
-    // `worth` = the problem is big enough for the fork/join events to pay off
+    // `worth` = the caller's measured choice (problem big enough for the ~20 us of fork / join
+    // latency, and a kernel mix that gains from running side by side); variant 4 forces the
+    // one-stream schedule, variant 6 the two-stream one
     explicit SideStream(hipStream_t main, bool worth = true) : main_(main), side_(main), p_(&slot())
     {
-        if (!p_->s || g_variant == 4 || !worth) return;       // no helper: stay on the main stream
+        if (!p_->s || g_variant == 4 || (!worth && g_variant != 6)) return;   // stay on `main`
         if (hipEventRecord(p_->fork, main_) == hipSuccess &&
             hipStreamWaitEvent(p_->s, p_->fork, 0) == hipSuccess)
             side_ = p_->s;
@@ -410,6 +412,13 @@ struct SideStream {
 #endif
 constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item
 constexpr size_t kSideStreamMinPoints = 1u << 20;   // below this the fork/join costs more than it hides
+// Two streams pay for fp32 storage (C2: 283 -> 270 us per step) and not for bf16 (229 -> 234 us):
+// every cross-stream dependency costs ~20 us of event latency and the kernels mostly contend
+// for the same CUs (rocprofv3 timelines).
+template <typename ST> inline bool side_stream_worth(const Dims &d)
+{
+    return sizeof(ST) == 4 && d.n_qh() * d.L * d.P >= kSideStreamMinPoints;
+}
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -531,11 +540,11 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     float *partials = (float *)(ws + w.partials);
-    // grad_loc / grad_weight (query-major gathers) do not depend on the binning: they are launched
-    // on the library's helper stream, next to the bin passes and the accumulate kernel.  Fork/join
-    // with events, so the caller still sees one in-order stream (also valid under stream capture).
-    // (Measured gain of the overlap: none to a few percent -- DESIGN.md 4.3.)
-    SideStream side(st, d.n_qh() * d.L * d.P >= kSideStreamMinPoints);
+    // grad_loc / grad_weight (query-major gathers) do not depend on the binning: where it pays
+    // (side_stream_worth) they are launched on the library's helper stream, next to the bin
+    // passes and the accumulate kernel.  Fork/join with events, so the caller still sees one
+    // in-order stream (also valid under stream capture).
+    SideStream side(st, side_stream_worth<ST>(d));
     if (!plan_ready) launch_binning(loc, d, plan, w, ws, st);
     {
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
@@ -666,7 +675,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         ok = workspace_bytes >= w.total;
     }
     if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
-    SideStream side(st, d.n_qh() * d.L * d.P >= kSideStreamMinPoints);
+    SideStream side(st, side_stream_worth<ST>(d));
     launch_binning(loc, d, plan, w, (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     side.join();

@@ -225,10 +225,11 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
  *   2 = first-generation fast kernels with fp atomics (error if the shape does not qualify;
  *       never the binned backward),
  *   3 = binned backward required (error if not eligible),
- *   4 = like 0 but the backward runs on one stream (no helper stream; used for per-kernel
- *       timing),
+ *   4 = like 0 but everything runs on the caller's stream (no helper stream),
  *   5 = like 0 but the instance forward with few (query, head) pairs keeps the workgroup
  *       split of the points instead of the one-wave-per-pair kernel.
+ *   6 = like 0 but the helper stream is always used (point gradients next to binning /
+ *       accumulate, binning next to the training forward).  0 picks 4 or 6 per storage type.
  * Returns the previous value.
  */
 int boxattn_set_variant(int variant);

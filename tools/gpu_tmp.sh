@@ -1,7 +1,6 @@
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for w in C3 C3p; do for dt in fp32 bf16; do
-echo -n "$w $dt: "; timeout 300 python bench.py --steps 40 --warmup 10 --workload $w --dtype $dt --no-cpu-baseline 2>&1 | tail -1 | python -c "
+for dt in bf16 fp32; do for v in 0 4 6; do
+echo -n "$dt variant $v: "; timeout 300 python bench.py --steps 100 --warmup 20 --variant $v --dtype $dt --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); r=d['roofline']
-print(d['value'], d['ms_per_step'], 'fwd_ms', r['fwd_ms'], 'bwd_ms', r['bwd_ms'], {k: round(1e3*v['avg_ms'],1) for k,v in r['kernels'].items()})"
+d=json.loads(sys.stdin.readline()); r=d['roofline']; print(d['value'], d['ms_per_step'], r['kernel'], r['frac'], {k: round(1e3*v['avg_ms'],1) for k,v in r['kernels'].items()})"
 done; done
