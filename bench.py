@@ -184,6 +184,22 @@ def make_step(inp):
     return step
 
 
+def graph_step(step):
+    """The same step as one HIP graph launch (capture after a warm-up on a side stream)."""
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            keep = step()                  # outputs stay alive with the graph
+    torch.cuda.current_stream().wait_stream(side)
+    graph._keep = keep
+    return graph.replay
+
+
 def time_phases(inp, iters=20):
     """fwd-only and bwd-only device time (ms, median) with events on the op's stream."""
     from boxer_amd import ops
@@ -321,6 +337,8 @@ def main():
     ap.add_argument("--inputs", default="model", choices=["model", "test"])
     ap.add_argument("--batch", type=int, default=BATCH,
                     help="images per GPU (the headline line uses the default)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in a HIP graph and time replays (not the headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
     args = ap.parse_args()
@@ -346,8 +364,12 @@ def main():
     inp = make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch,
                       seed=rank)
     step = make_step(inp)
+    eager_step = step
+    if args.graph:
+        step = graph_step(step)
 
     elapsed = run_timed(step, args.steps, args.warmup, torch.cuda.synchronize, dist, device)
+    step = eager_step                      # the per-kernel profile needs the launches themselves
 
     np_rank = n_points(inp["dims"])
     value, ms_per_step = throughput(elapsed, np_rank, world, args.steps)
@@ -394,6 +416,7 @@ def main():
             "value": round(value, 4), "unit": "Gsample-points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "launch": "hip-graph replay" if args.graph else "eager",
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s-attn fwd+bwd, levels %s, Lq=%d, H=%d, C=%d, P=%d, "
                                    "B=%d images per GPU, inputs=%s" % (

@@ -521,6 +521,53 @@ def test_modules_with_fused_grid():
                                        msg=lambda s_, n=name, w=what: "%s %s: %s" % (n, w, s_))
 
 
+# ------------------------------------------------------------------ HIP graph capture
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_backward_under_graph_capture(dtype):
+    """The training forward + backward are capturable in a HIP graph (no hidden synchronisation,
+    allocation or host read inside the library; the helper stream is forked / joined with events,
+    which capture follows) and the replay reproduces the eager results on new input values."""
+    from boxer_amd import ops
+    g = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 333, 4, seed=21)
+    dev_ = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).cuda().to(dt) if dt else \
+        torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    value = dev_(g["value"], dtype)
+    shapes, lsi = dev_(g["shapes"]), dev_(g["lsi"])
+    loc, attn = dev_(g["loc"], torch.float32), dev_(g["attn"], torch.float32)
+    gout = dev_(g["grad_out"], dtype)
+
+    def run():
+        out, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
+        gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)
+        return out, gv, gl, ga
+
+    for _ in range(3):                                       # warm-up: host tables, allocator
+        eager = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            captured = run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b_, name in zip(captured, eager, ("out", "grad_value", "grad_loc", "grad_attn")):
+        close(a, b_.double().cpu().numpy(), dtype if name in ("out", "grad_value") else torch.float32,
+              "replay " + name)
+    # new values in the same buffers: the graph recomputes (the plan depends on loc only)
+    value.mul_(0.5)
+    gout.mul_(2.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = run()
+    torch.cuda.synchronize()
+    for a, b_, name in zip(captured, want, ("out", "grad_value", "grad_loc", "grad_attn")):
+        close(a, b_.double().cpu().numpy(), dtype if name in ("out", "grad_value") else torch.float32,
+              "replay-2 " + name)
+
+
 # ------------------------------------------------------------------ full-size properties
 def test_full_size_linearity_and_checksums():
     """BASELINE configs[1] (C2) at full size, through size-independent properties:
