@@ -521,6 +521,48 @@ def test_modules_with_fused_grid():
                                        msg=lambda s_, n=name, w=what: "%s %s: %s" % (n, w, s_))
 
 
+# ------------------------------------------------------------------ randomised shape sweep
+def _sweep_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        L = int(rng.choice([1, 2, 3, 5, 8]))
+        shapes = [(int(rng.integers(1, 23)), int(rng.integers(1, 23))) for _ in range(L)]
+        cases.append((shapes, int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 4, 8])),
+                      int(rng.choice([16, 32, 64])), int(rng.choice([1, 7, 64, 257])),
+                      int(rng.choice([1, 4, 9, 16]))))
+    return cases
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("idx", range(12))
+def test_random_shape_sweep(idx, dtype):
+    """Random level sets (1..8 levels, maps from 1x1 to 22x22, so every block-edge and
+    one-pixel-level case occurs), heads, channels, query and point counts: box and instance
+    attention against the C oracle, locations partly outside [0, 1]."""
+    cfg = _sweep_cases(12, seed=2024)[idx]
+    g = _seeded(*cfg, seed=300 + idx, lo=-0.2, hi=1.2)
+    want_out = oc.box_attn_forward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"])
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    out, gv, gl, ga = run_box(g, dtype, "auto")
+    close(out, want_out, dtype, "out %r" % (cfg,))
+    close(gv, want[0], dtype, "grad_value %r" % (cfg,))
+    close(gl, want[1], torch.float32, "grad_loc %r" % (cfg,), ignore=g["on_edge"])
+    close(ga, want[2], torch.float32, "grad_attn %r" % (cfg,))
+    want_out, want_mask = oc.instance_attn_forward(g["value"], g["shapes"], g["lsi"], g["loc"],
+                                                   g["spatial_w"], g["level_w"])
+    want = oc.instance_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"],
+                                     g["spatial_w"], g["level_w"], g["grad_out"], g["grad_mask"])
+    out, mask, gv, gl, gs, glw = run_inst(g, dtype, "auto")
+    close(out, want_out, dtype, "inst out %r" % (cfg,))
+    close(mask, want_mask, dtype, "inst mask %r" % (cfg,))
+    close(gv, want[0], dtype, "inst grad_value %r" % (cfg,))
+    close(gl, want[1], torch.float32, "inst grad_loc %r" % (cfg,), ignore=g["on_edge"])
+    close(gs, want[2], torch.float32, "inst grad_spatial %r" % (cfg,))
+    close(glw, want[3], torch.float32, "inst grad_level %r" % (cfg,))
+
+
 # ------------------------------------------------------------------ HIP graph capture
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_forward_backward_under_graph_capture(dtype):
