@@ -342,7 +342,8 @@ void binned_accumulate_kernel(
     // row R of the stages is all zeros: the target of padded (unused) list entries
     __shared__ __attribute__((aligned(16))) unsigned char gstage[(R + 1) * RS];
     __shared__ __attribute__((aligned(16))) unsigned char mstage[INST ? (R + 1) * RS : 16];
-    __shared__ __attribute__((aligned(16))) Entry ent[4 * R + 2 * UNR + 1];  // [4R+UNR] = dump slot
+    // 4 entries per record + the lists' padding + the prefetch overrun of the last step
+    __shared__ __attribute__((aligned(16))) Entry ent[4 * R + PB * (UNR - 1) + UNR];
     __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
 
     // Workgroup -> (slice, worker) so that all workers of a slice sit on ONE XCD (workgroup b
@@ -483,9 +484,13 @@ void binned_accumulate_kernel(
                         rank[i][k] = atomicAdd(&pcnt[pixk[i][k]], 1);
                 }
             wave_lds_sync();
-            {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips)
-                int ic = lane < PB ? pcnt[lane] : 0;
+            {   // inclusive scan of the 32 pixel counts with DPP row shifts (no LDS round trips).
+                // Every list is padded to a multiple of UNR entries with {weight 0, zero row}, so
+                // the walk below needs no per-entry "still inside my list" masking.
+                const int cnt = lane < PB ? pcnt[lane] : 0;
                 if (lane < PB) pcnt[lane] = 0;                  // ready for the next round
+                const int padded = (cnt + UNR - 1) / UNR * UNR;
+                int ic = padded;
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x111, 0xF, 0xF, true);   // row_shr:1
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x112, 0xF, 0xF, true);   // row_shr:2
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x114, 0xF, 0xF, true);   // row_shr:4
@@ -493,6 +498,13 @@ void binned_accumulate_kernel(
                 ic += __builtin_amdgcn_update_dpp(0, ic, 0x142, 0xA, 0xF, true);   // row_bcast:15
                 if (lane < PB) poff[lane + 1] = ic;
                 if (lane == 0) poff[0] = 0;
+                if (lane < PB) {
+                    const float zrow = __int_as_float(R * RS);
+                    for (int e = ic - padded + cnt; e < ic; ++e) {
+                        if constexpr (INST) ent[e] = make_float4(0.f, 0.f, zrow, 0.f);
+                        else ent[e] = make_float2(0.f, zrow);
+                    }
+                }
             }
             wave_lds_sync();
             // all list offsets first (one LDS round trip), then the predicated entry writes
@@ -506,7 +518,7 @@ void binned_accumulate_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (BOXATTN_TUNE_ABLATE == 2 || pixk[i][k] >= PB) continue;
-                    const float slot = __int_as_float(i * 64 + lane);
+                    const float slot = __int_as_float((i * 64 + lane) * RS);   // row's LDS offset
                     if constexpr (INST)
                         ent[epos[i][k]] =
                             make_float4(wk[i][k] * as_c[i], wk[i][k] * al_c[i], slot, 0.f);
@@ -515,8 +527,7 @@ void binned_accumulate_kernel(
                 }
             wave_lds_sync();
             // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
-            //      pixel's list, UNR entries per step (independent LDS reads in flight); the
-            //      padding of the last step reads the zero row with weight 0.
+            //      pixel's (padded) list, UNR entries per step (independent LDS reads in flight)
             const int e0 = poff[mypix], e1 = poff[mypix + 1];
             Entry en_n[UNR];                           // entries of the next step (prefetched)
 #pragma unroll
@@ -526,20 +537,19 @@ void binned_accumulate_kernel(
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     en[u] = en_n[u];
-                    en_n[u] = ent[e + UNR + u];        // may run past the list: masked below
+                    en_n[u] = ent[e + UNR + u];        // may run into the next list: not used then
                 }
                 float wa[UNR], wb[UNR];
-                int jj[UNR];
+                int jj[UNR];                           // LDS byte offset of the entry's row
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const bool live = e + u < e1;
-                    wa[u] = live ? en[u].x : 0.f;
+                    wa[u] = en[u].x;
                     if constexpr (INST) {
-                        wb[u] = live ? en[u].y : 0.f;
-                        jj[u] = live ? __float_as_int(en[u].z) : R;
+                        wb[u] = en[u].y;
+                        jj[u] = __float_as_int(en[u].z);
                     } else {
                         wb[u] = 0.f;
-                        jj[u] = live ? __float_as_int(en[u].y) : R;
+                        jj[u] = __float_as_int(en[u].y);
                     }
                 }
                 // rows as raw words, then packed math: one v_pk_fma_f32 per channel pair
@@ -547,7 +557,7 @@ void binned_accumulate_kernel(
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const u32x4 *gp = reinterpret_cast<const u32x4 *>(
-                        &gstage[jj[u] * RS + half * (CH * SB)]);
+                        &gstage[jj[u] + half * (CH * SB)]);
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
                         rw[u][q] = BOXATTN_TUNE_ABLATE == 4 ? u32x4{(unsigned)jj[u], 1u, 2u, 3u} : gp[q];
@@ -563,7 +573,7 @@ void binned_accumulate_kernel(
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
                         const u32x4 *mp = reinterpret_cast<const u32x4 *>(
-                            &mstage[jj[u] * RS + half * (CH * SB)]);
+                            &mstage[jj[u] + half * (CH * SB)]);
 #pragma unroll
                         for (int q = 0; q < NQ; ++q) rw[u][q] = mp[q];
                     }
