@@ -312,9 +312,12 @@ void binned_accumulate_kernel(
     constexpr int R = 64 * RPL;                        // records per round, RPL per lane
     constexpr int CH = C / 2;                          // channels per lane while summing
     constexpr int ROWB = C * (int)sizeof(ST);          // bytes of one upstream-gradient row
-    // Rows are staged in the storage type.  (Staging bf16 rows as fp32 saves the unpack in the
-    // summation loop but doubles the LDS bytes, and this kernel is LDS-bound: ~80 % LDS busy.)
-    constexpr int SB = (int)sizeof(ST);                // bytes per staged element
+    // Box attention: rows are staged in the storage type.  (Staging bf16 rows as fp32 saves the
+    // unpack in the summation loop but doubles the LDS bytes: slower.)  Instance attention: the
+    // two upstream rows of a record are combined while staging, t = a_s * g + a_l * g_mask
+    // (reference instance_attn_kernel.cuh:139), as fp32 -- one staged row and one weight per
+    // entry, exactly the box flavour's walk, instead of two of each.
+    constexpr int SB = INST ? 4 : (int)sizeof(ST);     // bytes per staged element
     constexpr int RS = C * SB + 16;                    // LDS row stride: row + pad (banks)
     constexpr int LPR = ROWB / 16;                     // lanes that fetch one row, 16 B each
     constexpr int RPP = 64 / LPR;                      // rows staged per pass
@@ -324,7 +327,7 @@ void binned_accumulate_kernel(
 #define BOXATTN_TUNE_UNR 2
 #endif
     constexpr int UNR = BOXATTN_TUNE_UNR;              // list entries handled per step
-    typedef typename std::conditional<INST, float4, float2>::type Entry;   // {w*a_s[, w*a_l], j}
+    typedef float2 Entry;                              // {weight, LDS offset of the staged row}
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // plain vector: stays in VGPRs
     constexpr int NQ = CH * SB / 16;                   // 16-byte pieces of a lane's half row
     // channels (2i, 2i+1) of a staged half row as two floats
@@ -341,7 +344,6 @@ void binned_accumulate_kernel(
     };
     // row R of the stages is all zeros: the target of padded (unused) list entries
     __shared__ __attribute__((aligned(16))) unsigned char gstage[(R + 1) * RS];
-    __shared__ __attribute__((aligned(16))) unsigned char mstage[INST ? (R + 1) * RS : 16];
     // 4 entries per record + the lists' padding + the prefetch overrun of the last step
     __shared__ __attribute__((aligned(16))) Entry ent[4 * R + PB * (UNR - 1) + UNR];
     __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
@@ -367,7 +369,6 @@ void binned_accumulate_kernel(
     if (lane <= PB) pcnt[lane] = 0;
     for (int i = lane; i < RS / 4; i += 64) {          // the zero rows
         reinterpret_cast<int *>(&gstage[R * RS])[i] = 0;
-        if constexpr (INST) reinterpret_cast<int *>(&mstage[R * RS])[i] = 0;
     }
 
     // Items are taken heaviest first.  The launch provides one workgroup per potential item, so
@@ -422,6 +423,11 @@ void binned_accumulate_kernel(
         auto stage_piece = [&](unsigned char *dst, u32x4 v) {
             *reinterpret_cast<u32x4 *>(dst) = v;
         };
+        auto fetched_elem = [](const u32x4 &v, int e) -> float {   // element e of a 16-byte piece
+            if constexpr (sizeof(ST) == 4) return __uint_as_float(v[e]);
+            else return (e & 1) ? __uint_as_float(v[e / 2] & 0xffff0000u)
+                                : __uint_as_float(v[e / 2] << 16);
+        };
 #define BOXATTN_FETCH_ROWS()                                                                    \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
@@ -433,11 +439,22 @@ void binned_accumulate_kernel(
                 *reinterpret_cast<const u32x4 *>(grad_mask + (size_t)mj_ * C + piece_ * EPL);   \
         }                                                                                       \
     }
-#define BOXATTN_STAGE_ROWS()                                                                    \
+#define BOXATTN_STAGE_ROWS(AS, AL)                                                              \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
-        stage_piece(&gstage[j_ * RS + piece_ * 16], grow[ps]);                                  \
-        if constexpr (INST) stage_piece(&mstage[j_ * RS + piece_ * 16], mrow[ps]);              \
+        if constexpr (!INST) {                                                                  \
+            stage_piece(&gstage[j_ * RS + piece_ * 16], grow[ps]);                              \
+        } else {                                                                                \
+            const float as_ = __shfl(AS[(ps * RPP) / 64], j_ % 64, 64);                         \
+            const float al_ = __shfl(AL[(ps * RPP) / 64], j_ % 64, 64);                         \
+            float t_[EPL];                                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < EPL; ++e_)                                  \
+                t_[e_] = as_ * fetched_elem(grow[ps], e_) + al_ * fetched_elem(mrow[ps], e_);   \
+            _Pragma("unroll") for (int e_ = 0; e_ < EPL; e_ += 4)                               \
+                stage_piece(&gstage[j_ * RS + piece_ * (EPL * 4) + e_ * 4],                     \
+                            u32x4{__float_as_uint(t_[e_]), __float_as_uint(t_[e_ + 1]),         \
+                                  __float_as_uint(t_[e_ + 2]), __float_as_uint(t_[e_ + 3])});   \
+        }                                                                                       \
     }
         float2 xy_c[RPL], xy_n[RPL];
         float as_c[RPL], al_c[RPL], as_n[RPL], al_n[RPL];
@@ -446,7 +463,7 @@ void binned_accumulate_kernel(
         fetch_point(fetch_ids(item.y), xy_c, as_c, al_c);
         if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_FETCH_ROWS() }
         Ids rec_n = fetch_ids(item.y + R);
-        if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS() }   // round 0 staged directly
+        if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS(as_c, al_c) }   // round 0 staged directly
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;         // wave-uniform
@@ -500,10 +517,7 @@ void binned_accumulate_kernel(
                 if (lane == 0) poff[0] = 0;
                 if (lane < PB) {
                     const float zrow = __int_as_float(R * RS);
-                    for (int e = ic - padded + cnt; e < ic; ++e) {
-                        if constexpr (INST) ent[e] = make_float4(0.f, 0.f, zrow, 0.f);
-                        else ent[e] = make_float2(0.f, zrow);
-                    }
+                    for (int e = ic - padded + cnt; e < ic; ++e) ent[e] = make_float2(0.f, zrow);
                 }
             }
             wave_lds_sync();
@@ -519,11 +533,8 @@ void binned_accumulate_kernel(
                 for (int k = 0; k < 4; ++k) {
                     if (BOXATTN_TUNE_ABLATE == 2 || pixk[i][k] >= PB) continue;
                     const float slot = __int_as_float((i * 64 + lane) * RS);   // row's LDS offset
-                    if constexpr (INST)
-                        ent[epos[i][k]] =
-                            make_float4(wk[i][k] * as_c[i], wk[i][k] * al_c[i], slot, 0.f);
-                    else
-                        ent[epos[i][k]] = make_float2(wk[i][k] * as_c[i], slot);
+                    // instance attention: both weights are already in the staged row
+                    ent[epos[i][k]] = make_float2(INST ? wk[i][k] : wk[i][k] * as_c[i], slot);
                 }
             wave_lds_sync();
             // ---- phase 2: lane = (destination pixel, channel half): sum w * row over the
@@ -539,18 +550,12 @@ void binned_accumulate_kernel(
                     en[u] = en_n[u];
                     en_n[u] = ent[e + UNR + u];        // may run into the next list: not used then
                 }
-                float wa[UNR], wb[UNR];
+                float wa[UNR];
                 int jj[UNR];                           // LDS byte offset of the entry's row
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     wa[u] = en[u].x;
-                    if constexpr (INST) {
-                        wb[u] = en[u].y;
-                        jj[u] = __float_as_int(en[u].z);
-                    } else {
-                        wb[u] = 0.f;
-                        jj[u] = __float_as_int(en[u].y);
-                    }
+                    jj[u] = __float_as_int(en[u].y);
                 }
                 // rows as raw words, then packed math: one v_pk_fma_f32 per channel pair
                 u32x4 rw[UNR][NQ];
@@ -569,26 +574,10 @@ void binned_accumulate_kernel(
                     for (int i = 0; i < CH / 2; ++i)
                         acc[i] = __builtin_elementwise_fma(w2, staged_pair(rw[u], i), acc[i]);
                 }
-                if constexpr (INST) {
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const u32x4 *mp = reinterpret_cast<const u32x4 *>(
-                            &mstage[jj[u] + half * (CH * SB)]);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) rw[u][q] = mp[q];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const f32x2 w2 = {wb[u], wb[u]};
-#pragma unroll
-                        for (int i = 0; i < CH / 2; ++i)
-                            acc[i] = __builtin_elementwise_fma(w2, staged_pair(rw[u], i), acc[i]);
-                    }
-                }
             }
             wave_lds_sync();
             if (more) {                                // stage round r+1 (rows have arrived)
-                if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS() }
+                if (BOXATTN_TUNE_ABLATE != 3) { BOXATTN_STAGE_ROWS(as_n, al_n) }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) { xy_c[i] = xy_n[i]; as_c[i] = as_n[i]; al_c[i] = al_n[i]; }
             }
