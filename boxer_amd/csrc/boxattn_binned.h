@@ -317,7 +317,11 @@ void binned_accumulate_kernel(
     // two upstream rows of a record are combined while staging, t = a_s * g + a_l * g_mask
     // (reference instance_attn_kernel.cuh:139), as fp32 -- one staged row and one weight per
     // entry, exactly the box flavour's walk, instead of two of each.
-    constexpr int SB = INST ? 4 : (int)sizeof(ST);     // bytes per staged element
+#ifndef BOXATTN_TUNE_STAGE_F32
+#define BOXATTN_TUNE_STAGE_F32 0
+#endif
+    constexpr bool kCvt = INST || (BOXATTN_TUNE_STAGE_F32 && sizeof(ST) == 2);   // staged as fp32
+    constexpr int SB = kCvt ? 4 : (int)sizeof(ST);     // bytes per staged element
     constexpr int RS = C * SB + 16;                    // LDS row stride: row + pad (banks)
     constexpr int LPR = ROWB / 16;                     // lanes that fetch one row, 16 B each
     constexpr int RPP = 64 / LPR;                      // rows staged per pass
@@ -442,14 +446,16 @@ void binned_accumulate_kernel(
 #define BOXATTN_STAGE_ROWS(AS, AL)                                                              \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
         const int j_ = ps * RPP + lane / LPR, piece_ = lane % LPR;                              \
-        if constexpr (!INST) {                                                                  \
+        if constexpr (!kCvt) {                                                                  \
             stage_piece(&gstage[j_ * RS + piece_ * 16], grow[ps]);                              \
         } else {                                                                                \
-            const float as_ = __shfl(AS[(ps * RPP) / 64], j_ % 64, 64);                         \
-            const float al_ = __shfl(AL[(ps * RPP) / 64], j_ % 64, 64);                         \
+            const float as_ = INST ? __shfl(AS[(ps * RPP) / 64], j_ % 64, 64) : 1.f;            \
+            const float al_ = INST ? __shfl(AL[(ps * RPP) / 64], j_ % 64, 64) : 0.f;            \
             float t_[EPL];                                                                      \
             _Pragma("unroll") for (int e_ = 0; e_ < EPL; ++e_)                                  \
-                t_[e_] = as_ * fetched_elem(grow[ps], e_) + al_ * fetched_elem(mrow[ps], e_);   \
+                t_[e_] = INST ? as_ * fetched_elem(grow[ps], e_) +                              \
+                                    al_ * fetched_elem(mrow[INST ? ps : 0], e_)                 \
+                              : fetched_elem(grow[ps], e_);                                     \
             _Pragma("unroll") for (int e_ = 0; e_ < EPL; e_ += 4)                               \
                 stage_piece(&gstage[j_ * RS + piece_ * (EPL * 4) + e_ * 4],                     \
                             u32x4{__float_as_uint(t_[e_]), __float_as_uint(t_[e_ + 1]),         \
