@@ -495,39 +495,46 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
             const u32x4_t my_off =
                 corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[lc], H, h, C, have);
             const u32x4_t my_wt = as_u32x4(s.hh * s.hw, s.hh * s.lw, s.lh * s.hw, s.lh * s.lw);
-            // ---- step B: the G lanes walk the G levels together
-            u32x4_t off[G], wt[G];
-            unsigned aas[G], aal[G];
-            RowT v[G][4];
+            // ---- step B: the G lanes walk the group's levels together, four at a time (a
+            //      group has G level slots; with fewer levels left the rest is skipped)
+            constexpr int UL = 4;
 #pragma unroll
-            for (int t = 0; t < G; ++t) {
-                off[t] = u32x4_t{group_bcast<G>(my_off.x, t, lane), group_bcast<G>(my_off.y, t, lane),
-                                 group_bcast<G>(my_off.z, t, lane), group_bcast<G>(my_off.w, t, lane)};
-                wt[t] = u32x4_t{group_bcast<G>(my_wt.x, t, lane), group_bcast<G>(my_wt.y, t, lane),
-                                group_bcast<G>(my_wt.z, t, lane), group_bcast<G>(my_wt.w, t, lane)};
-                aas[t] = group_bcast<G>(__float_as_uint(as), t, lane);
-                aal[t] = group_bcast<G>(__float_as_uint(al), t, lane);
-                row_load<ST, VEC, PSB>(rs, off[t].x + lane_off, v[t][0]);
-                row_load<ST, VEC, PSB>(rs, off[t].y + lane_off, v[t][1]);
-                row_load<ST, VEC, PSB>(rs, off[t].z + lane_off, v[t][2]);
-                row_load<ST, VEC, PSB>(rs, off[t].w + lane_off, v[t][3]);
-            }
-            loads_issued();
+            for (int t0 = 0; t0 < G; t0 += UL) {
+                if (l0 + t0 >= L) break;                         // wave-uniform
+                u32x4_t off[UL], wt[UL];
+                unsigned aas[UL], aal[UL];
+                RowT v[UL][4];
 #pragma unroll
-            for (int t = 0; t < G; ++t) {
-                f32x2 val[VEC / 2];
+                for (int u = 0; u < UL; ++u) {
+                    const int t = t0 + u;
+                    off[u] = u32x4_t{group_bcast<G>(my_off.x, t, lane), group_bcast<G>(my_off.y, t, lane),
+                                     group_bcast<G>(my_off.z, t, lane), group_bcast<G>(my_off.w, t, lane)};
+                    wt[u] = u32x4_t{group_bcast<G>(my_wt.x, t, lane), group_bcast<G>(my_wt.y, t, lane),
+                                    group_bcast<G>(my_wt.z, t, lane), group_bcast<G>(my_wt.w, t, lane)};
+                    aas[u] = group_bcast<G>(__float_as_uint(as), t, lane);
+                    aal[u] = group_bcast<G>(__float_as_uint(al), t, lane);
+                    row_load<ST, VEC, PSB>(rs, off[u].x + lane_off, v[u][0]);
+                    row_load<ST, VEC, PSB>(rs, off[u].y + lane_off, v[u][1]);
+                    row_load<ST, VEC, PSB>(rs, off[u].z + lane_off, v[u][2]);
+                    row_load<ST, VEC, PSB>(rs, off[u].w + lane_off, v[u][3]);
+                }
+                loads_issued();
 #pragma unroll
-                for (int k = 0; k < VEC / 2; ++k) val[k] = f32x2{0.f, 0.f};
-                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].x), v[t][0]);
-                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].y), v[t][1]);
-                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].z), v[t][2]);
-                row_axpy<ST, VEC>(val, __uint_as_float(wt[t].w), v[t][3]);
-                const float a_s = __uint_as_float(aas[t]), a_l = __uint_as_float(aal[t]);
-                const f32x2 as2 = {a_s, a_s}, al2 = {a_l, a_l};
+                for (int u = 0; u < UL; ++u) {
+                    f32x2 val[VEC / 2];
 #pragma unroll
-                for (int k = 0; k < VEC / 2; ++k) {
-                    acc[k] = __builtin_elementwise_fma(val[k], as2, acc[k]);
-                    macc[k] = __builtin_elementwise_fma(val[k], al2, macc[k]);
+                    for (int k = 0; k < VEC / 2; ++k) val[k] = f32x2{0.f, 0.f};
+                    row_axpy<ST, VEC>(val, __uint_as_float(wt[u].x), v[u][0]);
+                    row_axpy<ST, VEC>(val, __uint_as_float(wt[u].y), v[u][1]);
+                    row_axpy<ST, VEC>(val, __uint_as_float(wt[u].z), v[u][2]);
+                    row_axpy<ST, VEC>(val, __uint_as_float(wt[u].w), v[u][3]);
+                    const float a_s = __uint_as_float(aas[u]), a_l = __uint_as_float(aal[u]);
+                    const f32x2 as2 = {a_s, a_s}, al2 = {a_l, a_l};
+#pragma unroll
+                    for (int k = 0; k < VEC / 2; ++k) {
+                        acc[k] = __builtin_elementwise_fma(val[k], as2, acc[k]);
+                        macc[k] = __builtin_elementwise_fma(val[k], al2, macc[k]);
+                    }
                 }
             }
         }
