@@ -570,6 +570,13 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);   // channels of one piece
     __shared__ LevelTable lv;
     __shared__ u32x4_t geo_all[4][Tile::kSize];
+    // Box attention with L * P = 8 or 16 points per pair (BoxeR: 2x2 grids on 2 or 4 levels): the
+    // per-point results are collected per pair in LDS and written once, 16 / 32 contiguous bytes
+    // per lane.  (Written tile by tile -- 4-byte and 8-byte pieces per lane, 16 points of a pair
+    // in four separate instructions -- the kernel's HBM write traffic was twice its output.)
+    constexpr int kBufLP = 16;
+    constexpr bool kCanBuffer = !INST && (G == 4 || G == 8);
+    __shared__ float res_all[kCanBuffer ? 4 * PAIRS * kBufLP * 3 : 1];
     load_levels(lv, shapes, lsi, L);
 
     const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
@@ -602,6 +609,9 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     float2 xy_n = loc2[pt0 + min(t_begin + slot, LP - 1)];      // first tile
     float as_n = w_sp[pt0 + min(t_begin + slot, LP - 1)];
     float al_n = INST ? w_lv[pt0 + min(t_begin + slot, LP - 1)] : 0.f;
+    const bool buffered = kCanBuffer && gridDim.y == 1 && (LP == 16 || LP == 8) &&
+                          ((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0;
+    float *res = res_all + (kCanBuffer ? (wv * PAIRS + lane / G) * (kBufLP * 3) : 0);
     for (int t0 = t_begin; t0 < t_end; t0 += G) {
         // ---- step A (the lane keeps its point's geometry in registers for the finish)
         const int lp = t0 + slot;
@@ -688,9 +698,36 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                 gy = Hl * (s.hw * (t3 - t1) + s.lw * (t4 - t2));
                 grad_lv[i] = s.inside ? w1 * m1 + w2 * m2 + w3 * m3 + w4 * m4 : 0.f;
             }
+            if constexpr (kCanBuffer) {
+                if (buffered) {                               // wave-uniform
+                    res[lp] = s.inside ? gs : 0.f;
+                    res[kBufLP + 2 * lp] = s.inside ? gx : 0.f;
+                    res[kBufLP + 2 * lp + 1] = s.inside ? gy : 0.f;
+                    continue;
+                }
+            }
             grad_sp[i] = s.inside ? gs : 0.f;
             reinterpret_cast<float2 *>(grad_loc)[i] =
                 s.inside ? make_float2(gx, gy) : make_float2(0.f, 0.f);
+        }
+    }
+    if constexpr (kCanBuffer) {
+        if (buffered && active) {
+            wave_lds_sync();                                  // the pair's lanes wrote `res`
+            const int n = LP / G, p0 = slot * n;              // this lane's points of the pair: 1, 2 or 4
+            const float *r = res + kBufLP + 2 * p0;
+            float *gs = grad_sp + pt0 + p0, *gl = grad_loc + 2 * (pt0 + p0);
+            if (n == 4) {
+                *reinterpret_cast<float4 *>(gs) = make_float4(res[p0], res[p0 + 1], res[p0 + 2], res[p0 + 3]);
+                reinterpret_cast<float4 *>(gl)[0] = make_float4(r[0], r[1], r[2], r[3]);
+                reinterpret_cast<float4 *>(gl)[1] = make_float4(r[4], r[5], r[6], r[7]);
+            } else if (n == 2) {
+                *reinterpret_cast<float2 *>(gs) = make_float2(res[p0], res[p0 + 1]);
+                *reinterpret_cast<float4 *>(gl) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+                *gs = res[p0];
+                *reinterpret_cast<float2 *>(gl) = make_float2(r[0], r[1]);
+            }
         }
     }
 }
