@@ -169,3 +169,47 @@ def test_module_surface_matches_reference():
     m = Box3dAttention(d, 2, H, with_rotation=False, kernel_size=3)
     assert m.state_dict()["linear_box_weight"].shape == (2 * H * 4, d)
     assert m.state_dict()["kernel_indices"][0].tolist() == [-0.5, -0.5]     # /2, not /k
+
+
+# ------------------------------------------------------------------ box -> grid op (opt-in)
+def test_box_grid_op_rejects_bad_arguments():
+    from boxer_amd import ops
+    """Host-side validation of ops.box_grid_forward / _backward (no GPU needed: CPU tensors are
+    refused first, exactly like the four reference entry points)."""
+    ref = torch.rand(2, 5, 4)
+    off = torch.randn(2, 5, 3, 2, 4)
+    kidx = torch.rand(4, 2)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.box_grid_forward(ref, off, kidx)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.box_grid_backward(ref, off, kidx, None, 0, torch.rand(2, 5, 3, 2, 4, 2))
+
+
+def test_modules_fused_grid_flag_is_inert_on_cpu(oracle_functions):
+    """`fused_grid = True` only takes effect for CUDA tensors; everything else silently keeps the
+    reference's torch path (same outputs as without the flag)."""
+    from boxer_amd import BoxAttention
+    torch.manual_seed(3)
+    m = BoxAttention(32, 2, 4, 2)
+    with torch.no_grad():
+        m.linear_box_weight.normal_(0, 0.05)
+    shapes = torch.tensor([[6, 5], [3, 2]])
+    lsi = torch.tensor([0, 30])
+    q, v = torch.randn(2, 7, 32), torch.randn(2, 36, 32)
+    ref_w = torch.rand(2, 7, 4)
+    out0 = m(q, v, shapes, None, lsi, None, ref_w)[0]
+    m.fused_grid = True
+    out1 = m(q, v, shapes, None, lsi, None, ref_w)[0]
+    assert torch.equal(out0, out1)
+
+
+def test_bench_algorithmic_bytes():
+    """60 B (bf16) / 76 B (fp32) per sample point at C2."""
+    import bench
+    dims = dict(B=2, S=13294, H=8, C=32, L=4, Lq=13294, P=4)
+    npts = bench.n_points(dims)
+    assert npts == 3403264
+    for elem, per_point in ((2, 60.0), (4, 76.0)):
+        fwd, bwd, per_kernel = bench.algorithmic_bytes(dims, "box", elem)
+        assert abs((fwd + bwd) / npts - per_point) < 0.01
+        assert set(per_kernel) >= {"fwd", "bwd_points", "bwd_accumulate"}
