@@ -285,7 +285,7 @@ def cpu_baseline(workload, budget_s=20.0):
     t0 = time.perf_counter()
     once()                                            # warm-up (also sizes the loop)
     first = time.perf_counter() - t0
-    iters = max(1, min(50, int(budget_s / max(first, 1e-3)) - 1))
+    iters = max(1, min(400, int(budget_s / max(first, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(iters):
         once()
