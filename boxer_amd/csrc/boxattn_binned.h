@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part,
     const int wps = (n_wg + kScanSub - 1) / kScanSub;
     const int w_lo = sub * wps, w_hi = min(n_wg, w_lo + wps);
     int *sp = part + (size_t)s * n_wg * plan.nblk;
-    for (int k = threadIdx.x; k < plan.nblk; k += 256) {
+    // grid.z covers the blocks 256 at a time (big maps: thousands of blocks per slice)
+    for (int k = blockIdx.z * 256 + threadIdx.x; k < plan.nblk; k += 256 * gridDim.z) {
         int t[kScanWgPerSub], sum = 0;
 #pragma unroll
         for (int u = 0; u < kScanWgPerSub; ++u)
@@ -211,19 +212,20 @@ __global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part,
     }
 }
 
-__global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
+constexpr int kScanThreads = 1024;     // one workgroup per slice walks the blocks 1024 at a time
+__global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict__ subtot,
                                                        int *__restrict__ offsets,
                                                        int4 *__restrict__ items,
                                                        int4 *__restrict__ combos,
                                                        int *__restrict__ n_items, BinPlan plan)
 {
     // four running sums over the blocks: records, items, partial slots, chunked blocks
-    __shared__ int wsum[4][4];
+    __shared__ int wsum[4][kScanThreads / 64];
     __shared__ int carry[4];
     const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x < 4) carry[threadIdx.x] = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < plan.nblk; k0 += 256) {
+    for (int k0 = 0; k0 < plan.nblk; k0 += kScanThreads) {
         const int k = k0 + threadIdx.x;
         const bool live = k < plan.nblk;
         int c = 0;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(int *__restrict__ subtot,
                 combos[(size_t)s * plan.nblk + ex[3]] = make_int4(k, ex[2], nch, 0);
         }
         __syncthreads();
-        if (threadIdx.x == 255) {
+        if (threadIdx.x == kScanThreads - 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) carry[i] = ex[i] + v[i];
         }

@@ -491,6 +491,11 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
     w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
     w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
                                           (kScanSub * kScanWgPerSub));
+    // ... and every workgroup initialises, flushes and has scanned one counter per block: give it
+    // at least 4 points per block (few queries on a big map: 1 000 queries on 468 x 468 = 6 903
+    // blocks per slice now use 1 workgroup per slice instead of 67)
+    const long long lp = (long long)d.L * d.P;
+    w.q_per_wg = (int)std::max<long long>(w.q_per_wg, (4ll * p.nblk + lp - 1) / lp);
     w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
     size_t o = 0;
     w.n_items = o; o += align_up(ns * 2 * 4);
@@ -521,10 +526,11 @@ inline void launch_binning(const float *loc, const Dims &d, const BinPlan &plan,
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
     hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
                        d.P, w.q_per_wg, part, subtot, offsets, records);
-    hipLaunchKernelGGL(bin_scan_a_kernel, dim3(kScanSub, ns), dim3(256), 0, st, part, w.n_wg,
-                       subtot, plan);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(256), 0, st, subtot, offsets, items, combos,
-                       n_items, plan);
+    hipLaunchKernelGGL(bin_scan_a_kernel,
+                       dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
+                       part, w.n_wg, subtot, plan);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items,
+                       combos, n_items, plan);
     hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
                        d.P, w.q_per_wg, part, subtot, offsets, records);
 }
