@@ -584,7 +584,12 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // persistent-waves version with a software queue was 15 % slower).  The
     // kernel maps workgroups to (slice, worker) itself (XCD affinity), hence the 8-aligned grid.
     const int ns8 = (ns + 7) / 8 * 8;
-    const int wg_per_slice = std::max(1, plan.item_cap);
+#ifndef BOXATTN_TUNE_ACC_WG_CAP
+#define BOXATTN_TUNE_ACC_WG_CAP 3072   // per slice; beyond that a workgroup takes several items (big, mostly empty maps)
+#endif
+    const int wg_per_slice = BOXATTN_TUNE_ACC_WG_CAP
+                                 ? std::min(BOXATTN_TUNE_ACC_WG_CAP, std::max(1, plan.item_cap))
+                                 : std::max(1, plan.item_cap);
     {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
         // records per lane and round: one is best for every flavour now that the bin passes
