@@ -811,7 +811,8 @@ int boxattn_abi_version(void) { return BOXATTN_ABI_VERSION; }
 const char *boxattn_build_info(void)
 {
     return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
-           " | kernels: generic{f32,f64,bf16}, fast{f32,bf16} VEC=4 G={4,8,16}, binned-bwd{f32,bf16}";
+           " | kernels: generic{f32,f64,bf16}, gather{f32 4ch/lane, bf16 8ch/lane} C={16,32,64}, "
+           "binned-bwd{f32,bf16}, box-grid{f32} | abi 5";
 }
 
 int boxattn_profile_begin(void)
