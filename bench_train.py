@@ -45,33 +45,43 @@ class EncoderLayer(nn.Module):
 
 
 class DecoderLayer(nn.Module):
-    """Self-attention over the object queries, box cross-attention into the memory, FFN."""
+    """Self-attention over the object queries, box cross-attention into the memory, FFN.
+    With `mask_cls` (InstanceAttention, kernel 14: the instance-segmentation decoder,
+    box_transformer.py:381-384) the cross-attention also returns the per-point RoI features,
+    which are handed back so that their branch takes part in the backward."""
 
-    def __init__(self, attn_cls, d_model, n_head, n_level, d_ffn):
+    def __init__(self, attn_cls, d_model, n_head, n_level, d_ffn, mask_cls=None):
         super().__init__()
         self.self_attn = nn.MultiheadAttention(d_model, n_head)
-        self.cross_attn = attn_cls(d_model, n_level, n_head)
+        self.use_mask = mask_cls is not None
+        if self.use_mask:
+            self.cross_attn = mask_cls(d_model, n_level, n_head, 14)
+            self.cross_attn.inferencing = False
+        else:
+            self.cross_attn = attn_cls(d_model, n_level, n_head)
         self.linear1, self.linear2 = nn.Linear(d_model, d_ffn), nn.Linear(d_ffn, d_model)
         self.norm1, self.norm2, self.norm3 = (nn.LayerNorm(d_model) for _ in range(3))
 
     def forward(self, tgt, query_pos, memory, shapes, mask, lsi, ratios, ref_windows):
         qk = (tgt + query_pos).transpose(0, 1)
         tgt = self.norm1(tgt + self.self_attn(qk, qk, tgt.transpose(0, 1))[0].transpose(0, 1))
-        tgt = self.norm2(tgt + self.cross_attn(tgt + query_pos, memory, shapes, mask, lsi,
-                                               ratios, ref_windows)[0])
-        return self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        res = self.cross_attn(tgt + query_pos, memory, shapes, mask, lsi, ratios, ref_windows)
+        tgt = self.norm2(tgt + res[0])
+        tgt = self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return (tgt, res[1]) if self.use_mask else (tgt, None)
 
 
 class SyntheticBoxeR2D(nn.Module):
     def __init__(self, attn_cls, levels, d_model=256, n_head=8, d_ffn=1024, n_enc=6, n_dec=6,
-                 n_query=300, n_class=91):
+                 n_query=300, n_class=91, mask_cls=None):
         super().__init__()
         self.levels = levels
         n_level = len(levels)
         self.encoder = nn.ModuleList(EncoderLayer(attn_cls, d_model, n_head, n_level, d_ffn)
                                      for _ in range(n_enc))
-        self.decoder = nn.ModuleList(DecoderLayer(attn_cls, d_model, n_head, n_level, d_ffn)
+        self.decoder = nn.ModuleList(DecoderLayer(attn_cls, d_model, n_head, n_level, d_ffn, mask_cls)
                                      for _ in range(n_dec))
+        self.roi_head = nn.Linear(d_model, 1) if mask_cls is not None else None
         self.query_embed = nn.Embedding(n_query, d_model)
         self.query_pos = nn.Embedding(n_query, d_model)
         self.query_ref = nn.Embedding(n_query, 4)                 # logits of (cx, cy, w, h)
@@ -104,9 +114,13 @@ class SyntheticBoxeR2D(nn.Module):
         tgt = self.query_embed.weight[None].expand(b, -1, -1)
         qpos = self.query_pos.weight[None].expand(b, -1, -1)
         ref = self.query_ref.weight.sigmoid()[None].expand(b, -1, -1)
+        roi = None
         for layer in self.decoder:
-            tgt = layer(tgt, qpos, memory, *args, ref)
-        return self.class_head(tgt), self.box_head(tgt).sigmoid()
+            tgt, roi = layer(tgt, qpos, memory, *args, ref)
+        logits, boxes = self.class_head(tgt), self.box_head(tgt).sigmoid()
+        if roi is not None:                       # (B, Lq, 14, 14, d) -> mask logits (B, Lq, 14, 14)
+            return logits, boxes, self.roi_head(roi).squeeze(-1)
+        return logits, boxes
 
 
 def make_batch(levels, batch, d_model, device, seed):
@@ -122,9 +136,12 @@ def train_step(model, opt, batch, autocast_dtype=None):
     src, pos, cls_t, box_t = batch
     opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
-        logits, boxes = model(src, pos)
+        out = model(src, pos)
+    logits, boxes = out[0], out[1]
     loss = F.mse_loss(logits.float(), cls_t[:, :logits.size(1)]) + \
         F.l1_loss(boxes.float(), box_t[:, :boxes.size(1)])
+    if len(out) == 3:                                 # dummy mask loss on the RoI branch
+        loss = loss + out[2].float().square().mean()
     loss.backward()
     opt.step()
     return loss.detach()
@@ -139,10 +156,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
                     help="bf16: autocast for the dense layers + the operator's native bf16 mode")
     ap.add_argument("--fused-grid", action="store_true")
+    ap.add_argument("--mask-decoder", action="store_true",
+                    help="InstanceAttention (14x14) in the decoder: the instance-segmentation model")
     ap.add_argument("--layers", type=int, default=6)
     args = ap.parse_args()
 
-    from boxer_amd import BoxAttention, _lib
+    from boxer_amd import BoxAttention, InstanceAttention, _lib
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,10 +175,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     torch.manual_seed(0)                                     # same initial weights on all ranks
-    model = SyntheticBoxeR2D(BoxAttention, LEVELS_COCO, n_enc=args.layers,
-                             n_dec=args.layers).to(device)
+    model = SyntheticBoxeR2D(BoxAttention, LEVELS_COCO, n_enc=args.layers, n_dec=args.layers,
+                             mask_cls=InstanceAttention if args.mask_decoder else None).to(device)
     for m in model.modules():
-        if isinstance(m, BoxAttention):
+        if isinstance(m, (BoxAttention, InstanceAttention)):
             m.native_bf16 = args.dtype == "bf16"
             m.fused_grid = args.fused_grid
             with torch.no_grad():                            # trained-like box offsets
@@ -199,7 +218,7 @@ def main():
             "metric": "synthetic BoxeR-2D training step (6+6 layers, COCO 1333x800 shapes)",
             "ms_per_step": round(ms_step, 3), "images_per_s": round(world * args.batch / ms_step * 1e3, 2),
             "n_gpus": world, "batch_per_gpu": args.batch, "dtype": args.dtype,
-            "fused_grid": args.fused_grid, "params_M": round(n_params / 1e6, 2),
+            "fused_grid": args.fused_grid, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
             "operator_kernels_ms_per_step": round(op_ms, 3),
             "operator_share": round(op_ms / ms_step, 3), "loss": round(float(loss), 4),
             "data": "synthetic", "scaling": "weak"}), flush=True)

@@ -33,14 +33,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(device):
+def _build(device, mask_decoder=False):
     import bench_train
-    from boxer_amd import BoxAttention
+    from boxer_amd import BoxAttention, InstanceAttention
     torch.manual_seed(0)
     model = bench_train.SyntheticBoxeR2D(BoxAttention, LEVELS, d_model=32, n_head=4, d_ffn=64,
-                                         n_enc=2, n_dec=2, n_query=10, n_class=7).to(device)
+                                         n_enc=2, n_dec=2, n_query=10, n_class=7,
+                                         mask_cls=InstanceAttention if mask_decoder else None
+                                         ).to(device)
     for m in model.modules():
-        if isinstance(m, BoxAttention):
+        if isinstance(m, (BoxAttention, InstanceAttention)):
             with torch.no_grad():
                 m.linear_box_weight.normal_(0, 0.05)
                 m.linear_attn_weight.normal_(0, 0.05)
@@ -96,12 +98,14 @@ def test_encoder_reference_windows():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native_bf16,fused", [(False, False), (True, True)])
-def test_training_step_on_gpu(native_bf16, fused):
-    from boxer_amd import BoxAttention
-    bench_train, model = _build("cuda")
+@pytest.mark.parametrize("native_bf16,fused,mask_decoder",
+                         [(False, False, False), (True, True, False), (False, True, True),
+                          (True, False, True)])
+def test_training_step_on_gpu(native_bf16, fused, mask_decoder):
+    from boxer_amd import BoxAttention, InstanceAttention
+    bench_train, model = _build("cuda", mask_decoder)
     for m in model.modules():
-        if isinstance(m, BoxAttention):
+        if isinstance(m, (BoxAttention, InstanceAttention)):
             m.native_bf16, m.fused_grid = native_bf16, fused
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     g = torch.Generator().manual_seed(1)
