@@ -51,7 +51,7 @@ WORKLOADS = {
     "C5pp": ([(234, 234), (117, 117)], 300, 4, "box3d"),      # BoxeR-3D decoder, learned rotation
 }
 H_HEADS, C_HEAD, BATCH = 8, 32, 2
-PREHEAT_STEPS = 50          # untimed steps (warm-up included) before the timed region, at least
+PREHEAT_STEPS = 100         # untimed steps (warm-up included) before the timed region, at least
 
 
 # --------------------------------------------------------------------------------------
@@ -374,7 +374,7 @@ def main():
     if args.graph:
         step = graph_step(step)
 
-    # Device pre-heat: the first ~50 steps after start-up run ~8 % slower than the steady state
+    # Device pre-heat: the first ~100 steps after start-up run up to ~8 % slower than the steady state
     # (clock ramp, tools/gpu_ramp.py).  With a short --warmup the gap is filled here, outside
     # the W warm-up + K timed steps of the protocol, so that the number is the steady-state one.
     preheat = max(0, PREHEAT_STEPS - args.warmup)
