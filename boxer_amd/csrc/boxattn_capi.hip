@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -365,11 +366,19 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 struct SideStream {
     static constexpr int kMaxDev = 16;
     struct PerDev { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    // The forward runs on the user's thread, the backward on an autograd worker: the lazy
+    // creation and every record + wait pair on the shared events are done under one lock.
+    static std::mutex &lock()
+    {
+        static std::mutex m;
+        return m;
+    }
     static PerDev &slot()
     {
         static PerDev devs[kMaxDev];
         int dev = 0;
         (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(lock());
         PerDev &p = devs[dev % kMaxDev];
         if (!p.s) {
             // lowest priority: the side kernel fills what the main chain leaves idle
@@ -391,6 +400,7 @@ struct SideStream {
     explicit SideStream(hipStream_t main, bool worth = true) : main_(main), side_(main), p_(&slot())
     {
         if (!p_->s || g_variant == 4 || (!worth && g_variant != 6)) return;   // stay on `main`
+        std::lock_guard<std::mutex> g(lock());
         if (hipEventRecord(p_->fork, main_) == hipSuccess &&
             hipStreamWaitEvent(p_->s, p_->fork, 0) == hipSuccess)
             side_ = p_->s;
@@ -399,6 +409,7 @@ struct SideStream {
     void join()
     {
         if (side_ == main_) return;
+        std::lock_guard<std::mutex> g(lock());
         (void)hipEventRecord(p_->join, side_);
         (void)hipStreamWaitEvent(main_, p_->join, 0);
         side_ = main_;
