@@ -8,14 +8,16 @@
 // owner that gathers its contributions:
 //
 //   1. bin_kernel<count>   one pass over the sampling locations: every sample point is
-//                          assigned to the 32-pixel blocks (8x4, per image, head, level)
-//                          its 2x2 footprint touches; per-workgroup LDS histograms, written
-//                          out densely per workgroup (no global atomics).
-//   2. bin_scan_kernel     per (image, head) slice: prefix over the workgroups and exclusive
-//                          scan over the blocks -> every workgroup's first slot in every bin,
-//                          and the work-item list (big bins are cut into chunks).
+//                          assigned to the blocks (up to 8x4 pixels, a balanced partition of
+//                          every level, per image and head) its 2x2 footprint touches;
+//                          per-workgroup LDS histograms, written out densely per workgroup
+//                          (no global atomics); queries interleaved over the workgroups.
+//   2. bin_scan_a_kernel, bin_scan_kernel   per (image, head) slice: prefix over the
+//                          workgroups and exclusive scan over the blocks -> every workgroup's
+//                          first slot in every bin, and the work-item list (big bins are cut
+//                          into chunks).
 //   3. bin_kernel<fill>    same pass again, now writing the point ids into their bins.
-//   4. bwd_fast_kernel<SCATTER=false> (boxattn_fast.h): grad_loc / grad_weight, query-major.
+//   4. pointgrad2_kernel (boxattn_gather2.h): grad_loc / grad_weight, query-major.
 //   5. binned_accumulate_kernel  one wavefront per work item: records -> geometry ->
 //                          per-pixel entry lists in LDS (integer LDS atomics for the ranks);
 //                          the records' upstream-gradient rows are staged once in LDS; each
