@@ -58,6 +58,27 @@ __device__ __forceinline__ int blk_of(int x, int nb, unsigned magic)
 // first coordinate of block c: ceil(c size / nb)
 __device__ __forceinline__ int blk_lo(int c, int size, int nb) { return (c * size + nb - 1) / nb; }
 
+// Origin, extent and level of a block in one word (computed once per block by the scan kernel:
+// five integer divisions that every work item used to repeat -- 5 % of the accumulate kernel).
+//   bits 0-11 oy, 12-23 ox, 24-25 bh - 1, 26-28 bw - 1, 29-31 level   (maps < 4096 x 4096)
+__device__ __forceinline__ unsigned pack_block_geo(const BinLevel &lv, int level, int blk)
+{
+    const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
+    const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
+    const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
+    return (unsigned)oy | ((unsigned)ox << 12) | ((unsigned)(bh - 1) << 24) |
+           ((unsigned)(bw - 1) << 26) | ((unsigned)level << 29);
+}
+struct BlockGeo { int oy, ox, bh, bw, level; };
+__device__ __forceinline__ BlockGeo unpack_block_geo(unsigned g)
+{
+    BlockGeo r;
+    r.oy = (int)(g & 0xFFFu); r.ox = (int)((g >> 12) & 0xFFFu);
+    r.bh = (int)((g >> 24) & 3u) + 1; r.bw = (int)((g >> 26) & 7u) + 1;
+    r.level = (int)(g >> 29);
+    return r;
+}
+
 #ifndef BOXATTN_TUNE_INTERLEAVE
 #define BOXATTN_TUNE_INTERLEAVE 1
 #endif
@@ -267,12 +288,21 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
         }
         if (live) {
             offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
+            int level = 0;
+#pragma unroll
+            for (int l = 1; l < kMaxBinLevels; ++l)
+                if (l < plan.L && k >= plan.lv[l].blk0) level = l;
+            BinLevel lv = plan.lv[0];
+#pragma unroll
+            for (int l = 1; l < kMaxBinLevels; ++l)
+                if (l == level) lv = plan.lv[l];
+            const int geo = (int)pack_block_geo(lv, level, k);
             for (int j = 0; j < nch; ++j)
                 items[(size_t)s * plan.item_cap + ex[1] + j] =     // record range inside the slice
-                    make_int4(k, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
+                    make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
                               nch > 1 ? ex[2] + j : -1);          // .w = partial slot or -1
             if (nch > 1)
-                combos[(size_t)s * plan.nblk + ex[3]] = make_int4(k, ex[2], nch, 0);
+                combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
         }
         __syncthreads();
         if (threadIdx.x == kScanThreads - 1) {
@@ -388,14 +418,12 @@ void binned_accumulate_kernel(
         // coarse levels sit at the end of the list and carry the long chunked items: take
         // them first so the tail of the kernel is made of short items
         const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];
-        const int blk = item.x;
+        const BlockGeo bg = unpack_block_geo((unsigned)item.x);
         BinLevel lv = plan.lv[0];                    // select, no dynamic indexing of kernel args
 #pragma unroll
         for (int k = 1; k < kMaxBinLevels; ++k)
-            if (k < plan.L && blk >= plan.lv[k].blk0) lv = plan.lv[k];
-        const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
-        const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
-        const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
+            if (k == bg.level) lv = plan.lv[k];
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
         const int *rec = records + (size_t)s * plan.rec_cap;   // item.y / .z index the slice
         (void)offsets;
         f32x2 acc[CH / 2];                           // channel pairs (2i, 2i+1) of this half
@@ -641,14 +669,13 @@ __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__rest
     const int n_comb = n_items[2 * s + 1];
     const int mypix = threadIdx.x >> 1, half = threadIdx.x & 1;
     for (int ci = blockIdx.x; ci < n_comb; ci += gridDim.x) {
-        const int4 cb = combos[(size_t)s * plan.nblk + ci];          // {block, first slot, nch}
+        const int4 cb = combos[(size_t)s * plan.nblk + ci];          // {block geometry, first slot, nch}
+        const BlockGeo bg = unpack_block_geo((unsigned)cb.x);
         BinLevel lv = plan.lv[0];
 #pragma unroll
         for (int k = 1; k < kMaxBinLevels; ++k)
-            if (k < plan.L && cb.x >= plan.lv[k].blk0) lv = plan.lv[k];
-        const int by = (cb.x - lv.blk0) / lv.nbx, bx = (cb.x - lv.blk0) % lv.nbx;
-        const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
-        const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
+            if (k == bg.level) lv = plan.lv[k];
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
         if (mypix / BW >= bh || mypix % BW >= bw) continue;
         const int yy = oy + mypix / BW, xx = ox + mypix % BW;
         float acc[CH];
