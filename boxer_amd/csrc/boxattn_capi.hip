@@ -95,9 +95,12 @@ template <typename ST, int G, int VEC> struct GatherUnroll {
     static constexpr int want = VEC == 8 ? u8 : u4;
     static constexpr int value = (want <= 0 || want > G) ? G : want;
 };
+#ifndef BOXATTN_TUNE_HEAD_XCD
+#define BOXATTN_TUNE_HEAD_XCD 1
+#endif
 inline unsigned div_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / d); }
 // index constants of the gather kernels; false if the problem is outside their 32-bit arithmetic
-inline bool gather_idx(const Dims &d, GatherIdx &ix)
+inline bool gather_idx(const Dims &d, GatherIdx &ix, size_t elem_bytes)
 {
     const size_t n_qh = d.n_qh();
     if (n_qh >= (1ull << 31) || (size_t)d.B * d.S >= (1ull << 31)) return false;
@@ -105,7 +108,20 @@ inline bool gather_idx(const Dims &d, GatherIdx &ix)
     ix.magic_h = div_magic((unsigned)d.H);
     ix.magic_lq = div_magic((unsigned)d.Lq);
     ix.rcp_p = 1.0f / (float)d.P;
+    // Head-per-XCD placement (pair_of_lane): measured +3..20 % when the queries sample far apart
+    // (decoder queries with big boxes, random locations) and -2..7 % for the encoder's local
+    // windows, where the contiguous query chunks already keep an XCD's rows together.  So: only
+    // for decoder-like shapes (few queries against the map) whose per-head rows fit an XCD's L2.
+    ix.head_xcd = (BOXATTN_TUNE_HEAD_XCD && d.H == 8 && (long long)d.Lq * 4 <= d.S &&
+                   (size_t)d.B * d.S * d.C * elem_bytes <= (3u << 20))
+                      ? 1u : 0u;
     return true;
+}
+// workgroups (4 waves of `pairs` pairs) of a gather kernel
+inline int gather_blocks(const Dims &d, const GatherIdx &ix, int pairs)
+{
+    if (ix.head_xcd) return 8 * ceil_div_sz((size_t)d.B * d.Lq, (size_t)pairs * 4);
+    return ceil_div_sz(d.n_qh(), (size_t)pairs * 4);
 }
 // (the 8-channel kernels are only instantiated for the storage types that select them)
 template <typename ST> struct GatherVec8 {
@@ -206,14 +222,14 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                         out)) {
             const size_t vbytes = d.n_value() * sizeof(ST);
             GatherIdx ix{};
-            const bool gen2 = g_variant != 2 && vbytes < kOobOffset && gather_idx(d, ix);   // buffer-load kernels
+            const bool gen2 = g_variant != 2 && vbytes < kOobOffset && gather_idx(d, ix, sizeof(ST));   // buffer-load kernels
             const GatherCfg cfg =
                 gen2 ? gather_cfg<ST>(d, aligned(value, 16) && aligned(out, 16) &&
                                          (!INST || aligned(mask, 16)))
                      : GatherCfg{fast_group(d), 4};
             const int G = cfg.G;
             const int pairs = kWave / G;
-            const int blocks = ceil_div_sz(n_qh, (size_t)pairs * 4);
+            const int blocks = gen2 ? gather_blocks(d, ix, pairs) : ceil_div_sz(n_qh, (size_t)pairs * 4);
             // instance attention with few queries and many points: split the points of a pair
             // over several workgroups (fp32 only: partial outs are combined with atomics)
             // (variant 5 = A/B switch: keep the split instead of the one-wave-per-pair kernel)
@@ -232,7 +248,8 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             // split when it gives more waves)
             if constexpr (INST) {
                 if (wide) {
-                    const int wblocks = ceil_div_sz(n_qh, 4);
+                    const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
+                                                    : ceil_div_sz(n_qh, 4);
 #define BOXATTN_FWD_WIDE(GG, VV)                                                              \
     hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(wblocks), dim3(256), 0, st,   \
                        value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out,    \
@@ -569,10 +586,10 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         const size_t n_qh = d.n_qh();
         const size_t vbytes = d.n_value() * sizeof(ST);
         GatherIdx ix{};
-        if (vbytes < kOobOffset && gather_idx(d, ix)) {
+        if (vbytes < kOobOffset && gather_idx(d, ix, sizeof(ST))) {
             const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
                                                     (!INST || aligned(grad_mask, 16)));
-            const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / cfg.G) * 4);
+            const int blocks = gather_blocks(d, ix, kWave / cfg.G);
             const int split = point_split(blocks, (d.L * d.P + cfg.G - 1) / cfg.G);
 #define BOXATTN_PG2(GG, VV)                                                                   \
     hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \

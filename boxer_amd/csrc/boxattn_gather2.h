@@ -228,7 +228,32 @@ struct GatherIdx {
     unsigned magic_h;     // floor(2^32 / H)   (divmod_magic)
     unsigned magic_lq;    // floor(2^32 / Lq)
     float rcp_p;          // 1.0f / P
+    unsigned head_xcd;    // 1: workgroup b works on head b % 8 (H == 8), see pair_of_lane()
 };
+
+// Which (query, head) pair a lane group works on.
+//   head_xcd = 0: consecutive pairs (a wave covers all heads of PAIRS / H queries), workgroups
+//                 re-mapped so that every XCD gets one contiguous chunk of the query range;
+//   head_xcd = 1 (H == 8): workgroup b -- which the hardware places on XCD b % 8 -- takes head
+//                 b % 8 and PAIRS consecutive queries per wave: an XCD's L2 then only ever holds
+//                 the rows of ONE head (1/8 of `value`), however far apart the queries sample.
+template <int PAIRS>
+__device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, int H, int j, int wv,
+                                                 bool &active)
+{
+    unsigned qh;
+    if (ix.head_xcd) {
+        const unsigned tile = (blockIdx.x / 8) * (blockDim.x / kWave) + wv;
+        const unsigned bq = tile * PAIRS + j;
+        active = bq < ix.n_qh / (unsigned)H;
+        qh = bq * (unsigned)H + blockIdx.x % 8;
+    } else {
+        const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
+        qh = (bid * (blockDim.x / kWave) + wv) * PAIRS + j;
+        active = qh < ix.n_qh;
+    }
+    return active ? qh : ix.n_qh - 1;
+}
 
 // ---------------------------------------------------------------------------------------
 // forward
@@ -249,13 +274,10 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     __shared__ u32x4_t geo_all[4][Tile::kSize];
     load_levels(lv, shapes, lsi, L);
 
-    const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);   // this group's part of the tile
-    const unsigned wave = bid * (blockDim.x / kWave) + wv;
-    unsigned qh = wave * PAIRS + lane / G;
-    const bool active = qh < ix.n_qh;
-    if (!active) qh = ix.n_qh - 1;
+    bool active;
+    const unsigned qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
     const int slot = lane % G;                      // step A: point slot; step B: channel chunk
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
@@ -457,7 +479,9 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     load_levels(lv, shapes, lsi, L);
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const unsigned qh = blockIdx.x * (blockDim.x / kWave) + wv;      // one pair per wave
+    unsigned qh = blockIdx.x * (blockDim.x / kWave) + wv;            // one pair per wave
+    if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
+        qh = ((blockIdx.x / 8) * (blockDim.x / kWave) + wv) * (unsigned)H + blockIdx.x % 8;
     if (qh >= ix.n_qh) return;                                          // wave-uniform
     const int slot = lane % G, grp = lane / G;
     unsigned bq, hu, b, qu;
@@ -579,13 +603,10 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     __shared__ float res_all[kCanBuffer ? 4 * PAIRS * kBufLP * 3 : 1];
     load_levels(lv, shapes, lsi, L);
 
-    const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);
-    const unsigned wave = bid * (blockDim.x / kWave) + wv;
-    unsigned qh = wave * PAIRS + lane / G;
-    const bool active = qh < ix.n_qh;
-    if (!active) qh = ix.n_qh - 1;
+    bool active;
+    const unsigned qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
     const int slot = lane % G;
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
