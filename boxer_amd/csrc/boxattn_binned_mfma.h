@@ -1,0 +1,246 @@
+// Step 5 of the destination-binned backward (boxattn_binned.h) on the matrix cores, for bf16
+// storage: the scatter-add of a round of 64 records into the 32 pixels of a block IS a small
+// matrix product
+//
+//     grad_value^T[c][pixel] += sum_k  G^T[c][k] * A^T[k][pixel]        k = record of the round
+//
+// with G = the records' upstream-gradient rows (bf16 as stored, exact) and A = the sparse
+// 32 x 64 matrix of bilinear weight x attention weight (<= 4 non-zeros per record).  The VALU
+// formulation (binned_accumulate_kernel) builds per-pixel entry lists with LDS atomics and walks
+// them; its length is set by the LONGEST of the 32 lists of a round (2x the mean) and by ~750
+// issued instructions per round.  Dense on v_mfma_f32_32x32x16_bf16 the same round is 8
+// instructions of 32 cycles -- ten times the multiply-adds, a fraction of the issue slots, and
+// no lists, ranks, atomics or imbalance at all.
+//
+// Precision: A is split into two bf16 terms, w = hi + lo (|w - hi - lo| <= 2^-17 |w|), and both
+// products accumulate in the MFMA's fp32 accumulator; bf16 x bf16 products are exact in fp32.
+// The result is the reference's sum to ~1e-5 relative per term, far inside the bf16 output
+// rounding.  One difference in kind: a dense product multiplies every row of the round by
+// every pixel's (mostly zero) weight, so a non-finite upstream gradient makes its whole block
+// NaN instead of its <= 4 pixels.
+//
+// Operand layout (32x32x16, K = 16 records per instruction): lane l holds 8 consecutive k
+// (k = 8 (l >> 5) + 0..7) of row / column l & 31 for BOTH operands, so both are kept
+// K-contiguous in LDS: G^T[c][k] (the rows are transposed while staging: ds_write_b16) and
+// A^T[pixel][k] (each record lane scatters its <= 4 weights, and clears them again after the
+// product -- no zero-fill per round).  C/D: lane l = pixel l & 31, register r = channel
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+#pragma once
+#include "boxattn_binned.h"
+
+namespace boxattn {
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C>
+__global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
+    const bf16_t *__restrict__ grad_out, const float *__restrict__ loc,
+    const float *__restrict__ w_sp, BinPlan plan, int S, int H, int Lq, int P,
+    const int4 *__restrict__ items, const int *__restrict__ n_items,
+    const int *__restrict__ records, bf16_t *__restrict__ grad_value,
+    float *__restrict__ partials)
+{
+    constexpr int BW = 8, PB = 32, R = 64;
+    constexpr int CP = C < 32 ? 32 : C;            // operand rows: channels padded to the MFMA's 32
+    constexpr int NCB = CP / 32;                   // 32-channel blocks
+    constexpr int ROWB = C * 2;                    // bytes of one upstream-gradient row
+    constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each
+    constexpr int RPP = 64 / LPR;                  // rows fetched per pass
+    constexpr int NPASS = R / RPP;
+    constexpr int GS = 68;    // ushorts per G^T row: 64 records + pad (34 dwords: transposing writes spread over the banks)
+    constexpr int AS = 72;    // ushorts per A^T row (36 dwords: 16-byte aligned rows, conflict-free operand reads)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) unsigned short gt[CP * GS];
+    // one A^T array: the hi term is scattered, multiplied, then overwritten in place by the lo term
+    __shared__ __attribute__((aligned(16))) unsigned short at[PB * AS];
+
+    // workgroup -> (slice, worker): all workers of a slice on one XCD (see binned_accumulate_kernel)
+    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = bid % 8, kq = bid / 8;
+    const int per_xcd = (n_slices + 7) / 8;
+    const int s = xcd + 8 * (kq % per_xcd);
+    const int worker = kq / per_xcd;
+    if (s >= n_slices || worker >= workers) return;
+    const int b = s / H, h = s % H;
+    const int LP = plan.L * P;
+    const int lane = threadIdx.x;
+    const int col = lane & 31, kb = lane >> 5;     // operand row / column, k-block
+    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    const int n_it = n_items[2 * s];
+    const int lp_mask = (1 << plan.lp_bits) - 1;
+
+    for (int i = lane; i < PB * AS / 2; i += 64) reinterpret_cast<unsigned int *>(at)[i] = 0u;
+    if (C < CP)                                     // the padding channels stay zero
+        for (int i = lane; i < CP * GS / 2; i += 64) reinterpret_cast<unsigned int *>(gt)[i] = 0u;
+    wave_lds_sync();
+
+    for (int it = worker; it < n_it; it += workers) {
+        const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];   // heaviest first
+        const BlockGeo bg = unpack_block_geo((unsigned)item.x);
+        BinLevel lv = plan.lv[0];
+#pragma unroll
+        for (int k = 1; k < kMaxBinLevels; ++k)
+            if (k == bg.level) lv = plan.lv[k];
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
+        const int *rec = records + (size_t)s * plan.rec_cap;
+        mfma_f32x16 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+        // software pipeline over rounds of 64 records, as in the VALU kernel: what round r+1
+        // needs from memory is issued at the top of round r.  Idle lanes use record 0 (valid,
+        // finite rows; their A columns are zero).
+        auto fetch_id = [&](int rr) -> int { return rr + lane < item.z ? rec[rr + lane] : 0; };
+        int row_n;
+        auto fetch_point = [&](int id, float2 &xy, float &a) {
+            const int q = id >> plan.lp_bits, lp = id & lp_mask;
+            row_n = (int)(((size_t)b * Lq + q) * H + h);
+            const size_t pid = (size_t)row_n * LP + lp;
+            xy = loc2[pid];
+            a = w_sp[pid];
+        };
+        u32x4 grow[NPASS];
+        auto fetch_rows = [&]() {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int j = ps * RPP + lane / LPR, piece = lane % LPR;
+                const int rj = __shfl(row_n, j, 64);
+                grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
+            }
+        };
+        auto stage_rows = [&]() {                  // G^T[8 piece + e][j] = row j, channel 8 piece + e
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int j = ps * RPP + lane / LPR, piece = lane % LPR;
+                unsigned short *dst = &gt[(piece * 8) * GS + j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    dst[e * GS] = (unsigned short)((e & 1) ? grow[ps][e / 2] >> 16
+                                                           : grow[ps][e / 2] & 0xffffu);
+            }
+        };
+        float2 xy_c, xy_n = make_float2(0.f, 0.f);
+        float a_c, a_n = 0.f;
+        fetch_point(fetch_id(item.y), xy_c, a_c);
+        fetch_rows();
+        int id_n = fetch_id(item.y + R);
+        stage_rows();
+        for (int rr = item.y; rr < item.z; rr += R) {
+            const int n = min(R, item.z - rr);
+            const bool more = rr + R < item.z;     // wave-uniform
+            if (more) {
+                fetch_point(id_n, xy_n, a_n);
+                fetch_rows();
+                id_n = fetch_id(rr + 2 * R);
+            }
+            // ---- lane = record: its <= 4 weights go to A^T[pixel][lane] as hi + lo bf16
+            const Sample<float> sm = locate<float>(xy_c.x, xy_c.y, lv.H, lv.W);
+            const float wk[4] = {sm.hh * sm.hw * a_c, sm.hh * sm.lw * a_c, sm.lh * sm.hw * a_c,
+                                 sm.lh * sm.lw * a_c};
+            const unsigned hi01 = pack_bf16x2(wk[0], wk[1]), hi23 = pack_bf16x2(wk[2], wk[3]);
+            const unsigned lo01 = pack_bf16x2(wk[0] - __uint_as_float(hi01 << 16),
+                                              wk[1] - __uint_as_float(hi01 & 0xffff0000u));
+            const unsigned lo23 = pack_bf16x2(wk[2] - __uint_as_float(hi23 << 16),
+                                              wk[3] - __uint_as_float(hi23 & 0xffff0000u));
+            const unsigned short whi[4] = {(unsigned short)(hi01 & 0xffffu), (unsigned short)(hi01 >> 16),
+                                           (unsigned short)(hi23 & 0xffffu), (unsigned short)(hi23 >> 16)};
+            const unsigned short wlo[4] = {(unsigned short)(lo01 & 0xffffu), (unsigned short)(lo01 >> 16),
+                                           (unsigned short)(lo23 & 0xffffu), (unsigned short)(lo23 >> 16)};
+            int slot[4];                            // A^T element of corner k, -1: not in this block
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = sm.y0 + (k >> 1), xx = sm.x0 + (k & 1);
+                const bool use = lane < n && sm.ok[k] && (unsigned)(yy - oy) < (unsigned)bh &&
+                                 (unsigned)(xx - ox) < (unsigned)bw;
+                slot[k] = use ? ((yy - oy) * BW + (xx - ox)) * AS + lane : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (slot[k] >= 0) at[slot[k]] = whi[k];
+            wave_lds_sync();
+            // ---- the product: 4 K-steps of 16 records per 32-channel block, hi term then lo term
+            mfma_bf16x8 g[R / 16][NCB];
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const int k0 = 16 * t + 8 * kb;
+                const mfma_bf16x8 p_hi = __builtin_bit_cast(
+                    mfma_bf16x8, *reinterpret_cast<const u32x4 *>(&at[col * AS + k0]));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const u32x2 *gp = reinterpret_cast<const u32x2 *>(&gt[(cb * 32 + col) * GS + k0]);
+                    const u32x2 g0 = gp[0], g1 = gp[1];
+                    g[t][cb] = __builtin_bit_cast(mfma_bf16x8, u32x4{g0.x, g0.y, g1.x, g1.y});
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_hi, acc[cb], 0, 0, 0);
+                }
+            }
+            wave_lds_sync();                         // a wave's LDS operations execute in order
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (slot[k] >= 0) at[slot[k]] = wlo[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const int k0 = 16 * t + 8 * kb;
+                const mfma_bf16x8 p_lo = __builtin_bit_cast(
+                    mfma_bf16x8, *reinterpret_cast<const u32x4 *>(&at[col * AS + k0]));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_lo, acc[cb], 0, 0, 0);
+            }
+            wave_lds_sync();
+            // ---- clear this round's weights, stage the next round's rows (they have arrived)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (slot[k] >= 0) at[slot[k]] = 0;
+            if (more) {
+                stage_rows();
+                xy_c = xy_n; a_c = a_n;
+            }
+            wave_lds_sync();
+        }
+        // ---- store.  Lane = pixel `col`; its registers hold channels 8 g + 4 kb + 0..3.
+        if (item.w < 0) {
+            // whole rows in the storage type: lanes l and l ^ 32 swap half of their packed
+            // pairs, so that each writes two 16-byte pieces (8 channels) of the pixel's row
+            const int py = col / BW, px = col % BW;
+            const bool live = py < bh && px < bw;
+            bf16_t *dst = grad_value +
+                          (((size_t)b * S + lv.start + (size_t)(oy + py) * lv.W + (ox + px)) * H + h) * C;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                unsigned pk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(acc[cb][2 * i], acc[cb][2 * i + 1]);
+                // kb = 0 keeps g = 0, 2 and needs the partner's halves of them; kb = 1: g = 1, 3
+                const unsigned r0 = __shfl_xor(kb ? pk[0] : pk[2], 32, 64);
+                const unsigned r1 = __shfl_xor(kb ? pk[1] : pk[3], 32, 64);
+                const unsigned r2 = __shfl_xor(kb ? pk[4] : pk[6], 32, 64);
+                const unsigned r3 = __shfl_xor(kb ? pk[5] : pk[7], 32, 64);
+                const u32x4 lo_piece = kb ? u32x4{r0, r1, pk[2], pk[3]} : u32x4{pk[0], pk[1], r0, r1};
+                const u32x4 hi_piece = kb ? u32x4{r2, r3, pk[6], pk[7]} : u32x4{pk[4], pk[5], r2, r3};
+                const int c_lo = cb * 32 + 8 * kb, c_hi = cb * 32 + 16 + 8 * kb;
+                if (live && c_lo < C) *reinterpret_cast<u32x4 *>(dst + c_lo) = lo_piece;
+                if (live && c_hi < C) *reinterpret_cast<u32x4 *>(dst + c_hi) = hi_piece;
+            }
+        } else {
+            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + col) * C;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cb * 32 + 8 * g + 4 * kb;
+                    if (c < C)
+                        *reinterpret_cast<float4 *>(dst + c) =
+                            make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2],
+                                        acc[cb][4 * g + 3]);
+                }
+        }
+    }
+}
+
+}  // namespace boxattn

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "boxattn_binned.h"
+#include "boxattn_binned_mfma.h"
 #include "boxattn_fast.h"
 #include "boxattn_gather2.h"
 #include "boxattn_generic.h"
@@ -629,9 +630,17 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
 #define BOXATTN_TUNE_RPL_F32 1
 #endif
         constexpr int kRpl = INST ? 1 : (sizeof(ST) == 2 ? BOXATTN_TUNE_RPL_BF16 : BOXATTN_TUNE_RPL_F32);
-        hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
-                           dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
-                           d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
+#ifndef BOXATTN_TUNE_ACC_MFMA
+#define BOXATTN_TUNE_ACC_MFMA 1    // bf16 box attention: the round's scatter-add as a dense MFMA product
+#endif
+        if constexpr (BOXATTN_TUNE_ACC_MFMA && !INST && std::is_same<ST, bf16_t>::value)
+            hipLaunchKernelGGL((binned_accumulate_mfma_kernel<4 * G>), dim3(wg_per_slice, ns8),
+                               dim3(64), 0, st, grad_out, loc, w_sp, plan, d.S, d.H, d.Lq, d.P,
+                               items, n_items, records, grad_value, partials);
+        else
+            hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
+                               dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
+                               d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
     }
     hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
                        n_items, partials, plan, d.S, d.H, grad_value);
