@@ -124,9 +124,16 @@ __device__ __forceinline__ void touched_blocks(const Sample<float> &s, const Bin
 #define BOXATTN_TUNE_BIN_THREADS 512
 #endif
 constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
-template <int BW, int BH, bool FILL>
-__global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc, BinPlan plan,
-                                                  int H, int Lq, int P, int q_per_wg,
+#ifndef BOXATTN_TUNE_BIN_XCD
+#define BOXATTN_TUNE_BIN_XCD 0     // all workgroups of a slice on one XCD: no gain measured (either record width)
+#endif
+// WIDE records (bf16 box attention, boxattn_binned_mfma.h): {point id, x, y, attention weight}
+// instead of the id alone, so that the accumulate kernel reads everything but the upstream row
+// from its (coalesced) record stream instead of gathering two more 128-byte lines per record.
+template <int BW, int BH, bool FILL, bool WIDE = false>
+__global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc,
+                                                  const float *__restrict__ w_sp, BinPlan plan,
+                                                  int H, int Lq, int P, int q_per_wg, int n_wg,
                                                   int *__restrict__ part,
                                                   const int *__restrict__ subtot,
                                                   const int *__restrict__ offsets,
@@ -138,31 +145,39 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     // ~200 k single-lane atomics on 226 cache lines), and the record order is deterministic.
     extern __shared__ int sh_bins[];
     int *hist = sh_bins;
-    const int s = blockIdx.y, b = s / H, h = s % H;
-    const int LP = plan.L * P;
-    // Workgroup w takes the queries w, w + n_wg, w + 2 n_wg, ...: every workgroup's records are
-    // then a uniform sample of the map, and so is any run of consecutive records of a bin.  The
-    // accumulate kernel works through a bin 64-128 records at a time with one lane per
-    // destination pixel; with contiguous query ranges a round's records came from neighbouring
-    // queries and piled up on a few pixels (longest per-pixel list 3.3x the mean; interleaved
-    // 2.1x; accumulate kernel 133 -> 103 us).
-#if BOXATTN_TUNE_INTERLEAVE
-    const int q0 = blockIdx.x, qstep = gridDim.x;
-    const int n_q = q0 < Lq ? (Lq - q0 + qstep - 1) / qstep : 0;
-    (void)q_per_wg;
+    // grid = (n_wg, slices rounded up to 8)
+#if BOXATTN_TUNE_BIN_XCD
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int per_xcd = (plan.n_slices + 7) / 8;
+    const int s = bid % 8 + 8 * ((bid / 8) % per_xcd), wg = (bid / 8) / per_xcd;
+    if (s >= plan.n_slices || wg >= n_wg) return;
 #else
-    const int q0 = blockIdx.x * q_per_wg, qstep = 1;
-    const int n_q = max(0, min(q0 + q_per_wg, Lq) - q0);
+    const int s = blockIdx.y, wg = blockIdx.x;
+    if (s >= plan.n_slices) return;
 #endif
+    const int b = s / H, h = s % H;
+    const int LP = plan.L * P;
+    // Narrow records (VALU accumulate kernel): workgroup w takes the queries w, w + n_wg,
+    // w + 2 n_wg, ...: every workgroup's records are then a uniform sample of the map, and so is
+    // any run of consecutive records of a bin.  That kernel works through a bin 64 records at a
+    // time with one lane per destination pixel; with contiguous query ranges a round's records
+    // came from neighbouring queries and piled up on a few pixels (longest per-pixel list 3.3x
+    // the mean; interleaved 2.1x; accumulate kernel 133 -> 103 us).
+    // Wide records (MFMA accumulate kernel: a dense product, indifferent to the order): contiguous
+    // query ranges, whose records land in few bins, in runs -- 27 -> 24 us for the fill pass.
+    constexpr bool kInterleave = BOXATTN_TUNE_INTERLEAVE && !WIDE;
+    const int q0 = kInterleave ? wg : wg * q_per_wg, qstep = kInterleave ? n_wg : 1;
+    const int n_q = kInterleave ? (q0 < Lq ? (Lq - q0 + qstep - 1) / qstep : 0)
+                                : max(0, min(q0 + q_per_wg, Lq) - q0);
     const int n_pts = n_q * LP;
-    int *mypart = part + ((size_t)s * gridDim.x + blockIdx.x) * plan.nblk;
+    int *mypart = part + ((size_t)s * n_wg + wg) * plan.nblk;
     __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane below (no select chains)
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
     }
-    const int wps = ((int)gridDim.x + kScanSub - 1) / kScanSub;       // as in bin_scan_a_kernel
-    const int *mysub = subtot + ((size_t)s * kScanSub + blockIdx.x / wps) * plan.nblk;
+    const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in bin_scan_a_kernel
+    const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
     for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x)
         hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
     __syncthreads();
@@ -172,15 +187,17 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
     const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
     const float rcp_lp = 1.0f / (float)LP;
-    int *rec = records + (size_t)s * plan.rec_cap;
+    int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
     for (int i0 = threadIdx.x; i0 < n_pts; i0 += blockDim.x * U) {
         float2 xy[U];
+        float wv[U];
         int lp[U], ql[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(i0 + u * (int)blockDim.x, n_pts - 1);
             divmod_small(i, LP, rcp_lp, ql[u], lp[u]);
             xy[u] = loc2[pid0 + ql[u] * qstride + lp[u]];
+            wv[u] = FILL && WIDE ? w_sp[pid0 + ql[u] * qstride + lp[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -195,7 +212,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
             for (int j = 0; j < 4; ++j) {
                 if (blk[j] >= 0) {
                     const int slot = atomicAdd(&hist[blk[j]], 1);      // LDS
-                    if (FILL) rec[slot] = ((q0 + ql[u] * qstep) << plan.lp_bits) | lp[u];
+                    if constexpr (FILL) {
+                        const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | lp[u];
+                        if constexpr (WIDE)
+                            reinterpret_cast<int4 *>(rec)[slot] =
+                                make_int4(id, __float_as_int(xy[u].x), __float_as_int(xy[u].y),
+                                          __float_as_int(wv[u]));
+                        else
+                            rec[slot] = id;
+                    }
                 }
             }
         }

@@ -30,13 +30,31 @@
 
 namespace boxattn {
 
+#ifndef BOXATTN_TUNE_MFMA_ABLATE
+#define BOXATTN_TUNE_MFMA_ABLATE 0   // timing experiments only (wrong results): 1 no staging writes,
+#endif                               // 2 no row gathers, 3 no MFMA, 4 no weight scatter
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
 
+// value of lane ^ D for D = 2, 4, 8 (inside a DPP row of 16 lanes; no LDS traffic)
+template <int D> __device__ __forceinline__ unsigned pair_exchange(unsigned x)
+{
+    static_assert(D == 2 || D == 4 || D == 8, "lanes per upstream row");
+    const int v = (int)x;
+    if constexpr (D == 2) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    } else if constexpr (D == 8) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    } else {
+        // row_shl:4 into the lanes 0-3 / 8-11 of each row, row_shr:4 into the lanes 4-7 / 12-15
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
-    const bf16_t *__restrict__ grad_out, const float *__restrict__ loc,
-    const float *__restrict__ w_sp, BinPlan plan, int S, int H, int Lq, int P,
+    const bf16_t *__restrict__ grad_out, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
     const int *__restrict__ records, bf16_t *__restrict__ grad_value,
     float *__restrict__ partials)
@@ -65,12 +83,9 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
     const int worker = kq / per_xcd;
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
-    const int LP = plan.L * P;
     const int lane = threadIdx.x;
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, k-block
-    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     const int n_it = n_items[2 * s];
-    const int lp_mask = (1 << plan.lp_bits) - 1;
 
     for (int i = lane; i < PB * AS / 2; i += 64) reinterpret_cast<unsigned int *>(at)[i] = 0u;
     if (C < CP)                                     // the padding channels stay zero
@@ -85,59 +100,69 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         for (int k = 1; k < kMaxBinLevels; ++k)
             if (k == bg.level) lv = plan.lv[k];
         const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
-        const int *rec = records + (size_t)s * plan.rec_cap;
+        // wide records {point id, x, y, attention weight} (bin_kernel<.., WIDE>), read coalesced
+        const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
         mfma_f32x16 acc[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 
-        // software pipeline over rounds of 64 records, as in the VALU kernel: what round r+1
-        // needs from memory is issued at the top of round r.  Idle lanes use record 0 (valid,
-        // finite rows; their A columns are zero).
-        auto fetch_id = [&](int rr) -> int { return rr + lane < item.z ? rec[rr + lane] : 0; };
-        int row_n;
-        auto fetch_point = [&](int id, float2 &xy, float &a) {
-            const int q = id >> plan.lp_bits, lp = id & lp_mask;
-            row_n = (int)(((size_t)b * Lq + q) * H + h);
-            const size_t pid = (size_t)row_n * LP + lp;
-            xy = loc2[pid];
-            a = w_sp[pid];
+        // software pipeline over rounds of 64 records: the records are read two rounds ahead,
+        // their upstream-gradient rows one round ahead (into registers; staged into LDS once the
+        // current round's operands have been read).  Idle lanes use query 0 (a valid, finite
+        // row; their A columns stay zero).
+        auto fetch_rec = [&](int rr) -> int4 {
+            return rr + lane < item.z ? rec[rr + lane] : make_int4(0, 0, 0, 0);
         };
-        u32x4 grow[NPASS];
-        auto fetch_rows = [&]() {
+        u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
+        auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {
+            if (BOXATTN_TUNE_MFMA_ABLATE == 2) return;
+            const int row = (int)(((size_t)b * Lq + (r.x >> plan.lp_bits)) * H + h);
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
-                const int rj = __shfl(row_n, j, 64);
+                const int rj = __shfl(row, j, 64);
                 grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
             }
         };
-        auto stage_rows = [&]() {                  // G^T[8 piece + e][j] = row j, channel 8 piece + e
+        // G^T[c][j] = row j, channel c.  Transposing 16-bit elements one ds_write_b16 at a time
+        // was 17 of this kernel's 51 us; instead the lanes of records j and j + 1 (same 16-byte
+        // piece) swap halves with DPP, and each writes whole dwords {G[j][c], G[j+1][c]}: the even
+        // record's lane for the piece's even channels, the odd one's for the odd channels.
+        auto stage_rows = [&]() {
+            if (BOXATTN_TUNE_MFMA_ABLATE == 1 || BOXATTN_TUNE_MFMA_ABLATE == 2) return;
+            const int odd = (lane / LPR) & 1;
+            const unsigned sel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selectors
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
-                unsigned short *dst = &gt[(piece * 8) * GS + j];
+                unsigned int *dst =
+                    reinterpret_cast<unsigned int *>(&gt[(piece * 8 + odd) * GS + (j & ~1)]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    dst[e * GS] = (unsigned short)((e & 1) ? grow[ps][e / 2] >> 16
-                                                           : grow[ps][e / 2] & 0xffffu);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned own = grow[ps][i];
+                    const unsigned oth = pair_exchange<LPR>(own);       // lane ^ LPR: record j ^ 1
+                    dst[i * GS] = __builtin_amdgcn_perm(oth, own, sel);   // rows 2 i + odd, GS ushorts apart
+                }
             }
         };
-        float2 xy_c, xy_n = make_float2(0.f, 0.f);
-        float a_c, a_n = 0.f;
-        fetch_point(fetch_id(item.y), xy_c, a_c);
-        fetch_rows();
-        int id_n = fetch_id(item.y + R);
+        // rows are gathered TWO rounds ahead (a wave with one round of rows in flight spent most
+        // of its time waiting for them), records three
+        int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
+        fetch_rows(rec_c, grow);
         stage_rows();
+        if (item.y + R < item.z) fetch_rows(rec_n, grow);
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;     // wave-uniform
-            if (more) {
-                fetch_point(id_n, xy_n, a_n);
-                fetch_rows();
-                id_n = fetch_id(rr + 2 * R);
+            int4 rec_n3 = make_int4(0, 0, 0, 0);
+            if (rr + 2 * R < item.z) {
+                fetch_rows(rec_n2, grow2);
+                rec_n3 = fetch_rec(rr + 3 * R);
             }
+            const float2 xy_c = make_float2(__int_as_float(rec_c.y), __int_as_float(rec_c.z));
+            const float a_c = __int_as_float(rec_c.w);
             // ---- lane = record: its <= 4 weights go to A^T[pixel][lane] as hi + lo bf16
             const Sample<float> sm = locate<float>(xy_c.x, xy_c.y, lv.H, lv.W);
             const float wk[4] = {sm.hh * sm.hw * a_c, sm.hh * sm.lw * a_c, sm.lh * sm.hw * a_c,
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0) at[slot[k]] = whi[k];
+                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = whi[k];
             wave_lds_sync();
             // ---- the product: 4 K-steps of 16 records per 32-channel block, hi term then lo term
             mfma_bf16x8 g[R / 16][NCB];
@@ -175,13 +200,16 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                     const u32x2 *gp = reinterpret_cast<const u32x2 *>(&gt[(cb * 32 + col) * GS + k0]);
                     const u32x2 g0 = gp[0], g1 = gp[1];
                     g[t][cb] = __builtin_bit_cast(mfma_bf16x8, u32x4{g0.x, g0.y, g1.x, g1.y});
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_hi, acc[cb], 0, 0, 0);
+                    if (BOXATTN_TUNE_MFMA_ABLATE != 3)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_hi, acc[cb], 0, 0, 0);
+                    else
+                        acc[cb][0] += __builtin_bit_cast(u32x4, g[t][cb])[0] + __builtin_bit_cast(u32x4, p_hi)[1];
                 }
             }
             wave_lds_sync();                         // a wave's LDS operations execute in order
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0) at[slot[k]] = wlo[k];
+                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = wlo[k];
             wave_lds_sync();
 #pragma unroll
             for (int t = 0; t < R / 16; ++t) {
@@ -190,16 +218,21 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                     mfma_bf16x8, *reinterpret_cast<const u32x4 *>(&at[col * AS + k0]));
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_lo, acc[cb], 0, 0, 0);
+                    if (BOXATTN_TUNE_MFMA_ABLATE != 3)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_lo, acc[cb], 0, 0, 0);
+                    else
+                        acc[cb][1] += __builtin_bit_cast(u32x4, p_lo)[2];
             }
             wave_lds_sync();
             // ---- clear this round's weights, stage the next round's rows (they have arrived)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0) at[slot[k]] = 0;
+                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = 0;
             if (more) {
                 stage_rows();
-                xy_c = xy_n; a_c = a_n;
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) grow[ps] = grow2[ps];
+                rec_c = rec_n; rec_n = rec_n2; rec_n2 = rec_n3;
             }
             wave_lds_sync();
         }

@@ -448,6 +448,14 @@ template <typename ST> inline bool side_stream_worth(const Dims &d)
 {
     return sizeof(ST) == 4 && d.n_qh() * d.L * d.P >= kSideStreamMinPoints;
 }
+#ifndef BOXATTN_TUNE_ACC_MFMA
+#define BOXATTN_TUNE_ACC_MFMA 1    // bf16 box attention: the round's scatter-add as a dense MFMA product
+#endif
+// flavours whose accumulate step runs on the matrix cores from wide records (boxattn_binned_mfma.h)
+template <typename ST, bool INST> constexpr bool wide_records()
+{
+    return BOXATTN_TUNE_ACC_MFMA && !INST && std::is_same<ST, bf16_t>::value;
+}
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -510,7 +518,9 @@ inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPl
     return make_plan_blocks(d, sh, ls, p);
 }
 
-inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
+// `wide`: 16-byte records {id, x, y, weight} (bf16 storage: the MFMA accumulate kernel) instead of
+// 4-byte point ids
+inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
 {
     const size_t ns = (size_t)d.B * d.H;
     WsLayout w;
@@ -533,7 +543,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
     w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
     w.items = o;   o += align_up(ns * p.item_cap * 16);
     w.combos = o;  o += align_up(ns * (size_t)p.nblk * 16);
-    w.records = o; o += align_up(ns * (size_t)p.rec_cap * 4);
+    w.records = o; o += align_up(ns * (size_t)p.rec_cap * (wide ? 16 : 4));
     w.partials = o; o += align_up(ns * (size_t)p.pslot_cap * 32 * d.C * 4);
     w.total = o;
     return w;
@@ -541,8 +551,9 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p)
 
 // Binning passes (count, two scans, fill) of the binned backward into the workspace.  They only
 // read the sampling locations, so the training forward can run them ahead of the backward.
-inline void launch_binning(const float *loc, const Dims &d, const BinPlan &plan, const WsLayout &w,
-                           char *ws, hipStream_t st)
+template <bool WIDE>
+inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
+                           const WsLayout &w, char *ws, hipStream_t st)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
@@ -550,18 +561,18 @@ inline void launch_binning(const float *loc, const Dims &d, const BinPlan &plan,
     int *n_items = (int *)(ws + w.n_items);      // every scratch word is written before it is read
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
-    const dim3 bgrid(w.n_wg, ns);
+    const dim3 bgrid(w.n_wg, (ns + 7) / 8 * 8);      // the kernel maps workgroups to (slice, worker)
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
-    hipLaunchKernelGGL((bin_kernel<BW, BH, false>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
-                       d.P, w.q_per_wg, part, subtot, offsets, records);
+    hipLaunchKernelGGL((bin_kernel<BW, BH, false, WIDE>), bgrid, dim3(kBinThreads), bsh, st, loc, w_sp,
+                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets, records);
     hipLaunchKernelGGL(bin_scan_a_kernel,
                        dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
                        part, w.n_wg, subtot, plan);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items,
                        combos, n_items, plan);
-    hipLaunchKernelGGL((bin_kernel<BW, BH, true>), bgrid, dim3(kBinThreads), bsh, st, loc, plan, d.H, d.Lq,
-                       d.P, w.q_per_wg, part, subtot, offsets, records);
+    hipLaunchKernelGGL((bin_kernel<BW, BH, true, WIDE>), bgrid, dim3(kBinThreads), bsh, st, loc, w_sp,
+                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets, records);
 }
 
 template <typename ST, int G, bool INST>
@@ -580,7 +591,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // passes and the accumulate kernel.  Fork/join with events, so the caller still sees one
     // in-order stream (also valid under stream capture).
     SideStream side(st, side_stream_worth<ST>(d));
-    if (!plan_ready) launch_binning(loc, d, plan, w, ws, st);
+    if (!plan_ready) launch_binning<wide_records<ST, INST>()>(loc, w_sp, d, plan, w, ws, st);
     {
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
@@ -630,13 +641,10 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
 #define BOXATTN_TUNE_RPL_F32 1
 #endif
         constexpr int kRpl = INST ? 1 : (sizeof(ST) == 2 ? BOXATTN_TUNE_RPL_BF16 : BOXATTN_TUNE_RPL_F32);
-#ifndef BOXATTN_TUNE_ACC_MFMA
-#define BOXATTN_TUNE_ACC_MFMA 1    // bf16 box attention: the round's scatter-add as a dense MFMA product
-#endif
-        if constexpr (BOXATTN_TUNE_ACC_MFMA && !INST && std::is_same<ST, bf16_t>::value)
+        if constexpr (wide_records<ST, INST>())
             hipLaunchKernelGGL((binned_accumulate_mfma_kernel<4 * G>), dim3(wg_per_slice, ns8),
-                               dim3(64), 0, st, grad_out, loc, w_sp, plan, d.S, d.H, d.Lq, d.P,
-                               items, n_items, records, grad_value, partials);
+                               dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
+                               records, grad_value, partials);
         else
             hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
                                dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
@@ -668,7 +676,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   aligned(workspace, 256) && aligned(grad_value, 16);
     WsLayout w{};
     if (binned) {
-        w = ws_layout(d, plan);
+        w = ws_layout(d, plan, kBf16);
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
@@ -719,12 +727,12 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
               aligned(workspace, 256) && aligned(loc, 8);
     WsLayout w{};
     if (ok) {
-        w = ws_layout(d, plan);
+        w = ws_layout(d, plan, std::is_same<ST, bf16_t>::value);
         ok = workspace_bytes >= w.total;
     }
     if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     SideStream side(st, side_stream_worth<ST>(d));
-    launch_binning(loc, d, plan, w, (char *)workspace, side.stream());
+    launch_binning<wide_records<ST, INST>()>(loc, w_sp, d, plan, w, (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     side.join();
     if (rc == 0 && plan_built) *plan_built = 1;
@@ -789,7 +797,7 @@ size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int 
     const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
     BinPlan plan;
     if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
-    return std::max(fallback, ws_layout(d, plan).total);
+    return std::max(fallback, ws_layout(d, plan, is_bf16 != 0).total);
 }
 
 int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
