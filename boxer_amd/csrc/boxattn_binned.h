@@ -18,13 +18,18 @@
 //                          into chunks).
 //   3. bin_kernel<fill>    same pass again, now writing the point ids into their bins.
 //   4. pointgrad2_kernel (boxattn_gather2.h): grad_loc / grad_weight, query-major.
-//   5. binned_accumulate_kernel  one wavefront per work item: records -> geometry ->
-//                          per-pixel entry lists in LDS (integer LDS atomics for the ranks);
-//                          the records' upstream-gradient rows are staged once in LDS; each
-//                          lane pair owns one destination pixel and sums (w*a) * row over its
-//                          list in registers; one plain coalesced row store per pixel in the
-//                          storage type.  Blocks cut into chunks (the coarse levels) write
-//                          fp32 partial tiles instead.
+//   5. accumulate, one wavefront per work item, two formulations:
+//      binned_accumulate_mfma_kernel (boxattn_binned_mfma.h; bf16 box attention): a round of 64
+//                          records x 32 pixels as a dense product on the matrix cores, from
+//                          wide records {id, x, y, weight};
+//      binned_accumulate_kernel (here; fp32 storage and instance attention): records ->
+//                          geometry -> per-pixel entry lists in LDS (integer LDS atomics for
+//                          the ranks); the records' upstream-gradient rows are staged once in
+//                          LDS; each lane pair owns one destination pixel and sums (w*a) * row
+//                          over its list in registers.
+//                          Either way: one plain coalesced row store per pixel in the storage
+//                          type; blocks cut into chunks (the coarse levels) write fp32 partial
+//                          tiles instead.
 //   6. combine_partials_kernel   sums the partial tiles of the chunked blocks.
 // No zero-fill, no conversion pass, no float atomics (run-to-run differences are limited to
 // the fp32 summation order inside a bin, which follows integer LDS atomics).
@@ -98,23 +103,27 @@ struct BinPlan {
 };
 
 // Blocks touched by the (valid part of the) 2x2 footprint of a sample: up to 2 block rows x 2
-// block columns.  Branch-free: always four candidates, `dump` for the unused ones.
-template <int BW, int BH>
-__device__ __forceinline__ void touched_blocks(const Sample<float> &s, const BinLevel &lv, int dump,
-                                               int (&blk)[4])
+// block columns, -1 for the unused candidates.  The valid rows of the footprint are exactly
+// {max(y0, 0), min(y0 + 1, H - 1)} (a point that passes the window test has y0 in [-1, H - 1]),
+// columns alike, so clamping replaces the per-corner validity logic.
+__device__ __forceinline__ void touched_blocks(float x, float y, const BinLevel &lv, int (&blk)[4])
 {
-    const bool ya = s.ok[0] || s.ok[1], yb = s.ok[2] || s.ok[3];
-    const bool xa = s.ok[0] || s.ok[2], xb = s.ok[1] || s.ok[3];
-    // only used when the row / column is valid
-    const int ra = blk_of(s.y0, lv.nby, lv.mh), rb = blk_of(s.y0 + 1, lv.nby, lv.mh);
-    const int ca = blk_of(s.x0, lv.nbx, lv.mw), cb = blk_of(s.x0 + 1, lv.nbx, lv.mw);
-    const bool use_rb = yb && (!ya || rb != ra);             // second row adds a new block row
-    const bool use_cb = xb && (!xa || cb != ca);
+    float h_im, w_im;
+    {
+#pragma clang fp contract(off)                   // two roundings, as in locate()
+        h_im = y * (float)lv.H - 0.5f;
+        w_im = x * (float)lv.W - 0.5f;
+    }
+    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W &&
+                        lv.H > 0 && lv.W > 0;
+    const int y0 = (int)floorf(inside ? h_im : 0.f), x0 = (int)floorf(inside ? w_im : 0.f);
+    const int ra = blk_of(max(y0, 0), lv.nby, lv.mh), rb = blk_of(min(y0 + 1, lv.H - 1), lv.nby, lv.mh);
+    const int ca = blk_of(max(x0, 0), lv.nbx, lv.mw), cb = blk_of(min(x0 + 1, lv.W - 1), lv.nbx, lv.mw);
     const int base_a = lv.blk0 + ra * lv.nbx, base_b = lv.blk0 + rb * lv.nbx;
-    blk[0] = (ya && xa) ? base_a + ca : dump;
-    blk[1] = (ya && use_cb) ? base_a + cb : dump;
-    blk[2] = (use_rb && xa) ? base_b + ca : dump;
-    blk[3] = (use_rb && use_cb) ? base_b + cb : dump;
+    blk[0] = inside ? base_a + ca : -1;
+    blk[1] = inside && cb != ca ? base_a + cb : -1;
+    blk[2] = inside && rb != ra ? base_b + ca : -1;
+    blk[3] = inside && rb != ra && cb != ca ? base_b + cb : -1;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     constexpr int U = 4;                          // points per thread per step (loads in flight)
     const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
     const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
-    const float rcp_lp = 1.0f / (float)LP;
+    const float rcp_lp = 1.0f / (float)LP, rcp_p = 1.0f / (float)P;
     int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
     for (int i0 = threadIdx.x; i0 < n_pts; i0 += blockDim.x * U) {
         float2 xy[U];
@@ -202,16 +211,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (i0 + u * (int)blockDim.x >= n_pts) break;
-            const BinLevel lv = s_lv[level_of(lp[u], P, plan.L)];
-            const Sample<float> sm = locate<float>(xy[u].x, xy[u].y, lv.H, lv.W);
+            const BinLevel lv = s_lv[(int)(((float)lp[u] + 0.5f) * rcp_p)];   // level = lp / P
             int blk[4];
-            touched_blocks<BW, BH>(sm, lv, -1, blk);
+            touched_blocks(xy[u].x, xy[u].y, lv, blk);
             // predicated, not redirected to a dump slot: same-address LDS atomics serialise per
             // lane, a shared dump slot made this kernel 1.6x slower
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (blk[j] >= 0) {
-                    const int slot = atomicAdd(&hist[blk[j]], 1);      // LDS
+#ifndef BOXATTN_TUNE_FILL_ABLATE
+#define BOXATTN_TUNE_FILL_ABLATE 0     // timing experiments only: 1 records into a 16 KiB window, 2 no record stores
+#endif
+                    int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
+                    if (BOXATTN_TUNE_FILL_ABLATE == 1) slot &= 1023;
+                    if (BOXATTN_TUNE_FILL_ABLATE == 2 && slot != -12345) continue;
                     if constexpr (FILL) {
                         const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | lp[u];
                         if constexpr (WIDE)

@@ -90,7 +90,8 @@ def _host_table(t):
 class BackwardPlan:
     """Opaque hand-over from a training forward to the matching backward: the scratch tensor in
     which the forward already binned the sample points (the binning only depends on the sampling
-    locations, so it runs concurrently with the forward kernel), plus what it is valid for."""
+    locations and -- bf16 box attention, whose records carry them -- the attention weights),
+    plus what it is valid for."""
 
     __slots__ = ("ws", "key")
 
@@ -98,8 +99,9 @@ class BackwardPlan:
         self.ws, self.key = ws, key
 
 
-def _plan_key(dims, loc):
-    return (tuple(dims), loc.data_ptr(), loc._version, loc.device.index)
+def _plan_key(dims, loc, weights):
+    return (tuple(dims), loc.device.index) + tuple((t.data_ptr(), t._version)
+                                                    for t in (loc,) + tuple(weights))
 
 
 def _workspace(value, shapes, lsi, dims):
@@ -111,7 +113,7 @@ def _workspace(value, shapes, lsi, dims):
     return ws, sh, ls
 
 
-def _forward_train(name, value, shapes, lsi, loc, dims, args):
+def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     """*_fwd_train_*: forward + (when the binned backward applies) the backward's plan."""
     import ctypes
     lib = _lib.load()
@@ -125,13 +127,13 @@ def _forward_train(name, value, shapes, lsi, loc, dims, args):
                 ctypes.addressof(built), stream)
     if rc != 0:
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
-    return BackwardPlan(ws, _plan_key(dims, loc)) if built.value else None
+    return BackwardPlan(ws, _plan_key(dims, loc, weights)) if built.value else None
 
 
-def _backward_with_workspace(name, value, shapes, lsi, loc, dims, args, plan=None):
+def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
     """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
     lib = _lib.load()
-    ready = int(plan is not None and plan.key == _plan_key(dims, loc))
+    ready = int(plan is not None and plan.key == _plan_key(dims, loc, weights))
     if ready:
         ws, sh, ls = plan.ws, _host_table(shapes), _host_table(lsi)
     else:
@@ -179,7 +181,8 @@ def box_attn_forward_train(value, spatial_shapes, level_start_index, sampling_lo
     if value.dtype == torch.float64:
         _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
         return out, None
-    plan = _forward_train("boxattn_fwd_train", value, spatial_shapes, level_start_index, loc, dims,
+    plan = _forward_train("boxattn_fwd_train", value, spatial_shapes, level_start_index, loc,
+                          (attn,), dims,
                           [value, spatial_shapes, level_start_index, loc, attn, *dims, out])
     return out, plan
 
@@ -203,7 +206,7 @@ def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, at
         _call("boxattn_bwd", value, *args)
     else:
         _backward_with_workspace("boxattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
-                                 dims, args, plan)
+                                 (attn,), dims, args, plan)
     return [grad_value, grad_loc, grad_attn]
 
 
@@ -235,7 +238,7 @@ def instance_attn_forward_train(value, spatial_shapes, level_start_index, sampli
         _call("instattn_fwd", value, *args)
         return [out, mask], None
     plan = _forward_train("instattn_fwd_train", value, spatial_shapes, level_start_index, loc,
-                          dims, args)
+                          (sw, lw), dims, args)
     return [out, mask], plan
 
 
@@ -262,7 +265,7 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
         _call("instattn_bwd", value, *args)
     else:
         _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
-                                 dims, args, plan)
+                                 (sw, lw), dims, args, plan)
     return [grad_value, grad_loc, grad_sw, grad_lw]
 
 

@@ -598,7 +598,7 @@ def test_forward_backward_under_graph_capture(dtype):
     for a, b_, name in zip(captured, eager, ("out", "grad_value", "grad_loc", "grad_attn")):
         close(a, b_.double().cpu().numpy(), dtype if name in ("out", "grad_value") else torch.float32,
               "replay " + name)
-    # new values in the same buffers: the graph recomputes (the plan depends on loc only)
+    # new values in the same buffers: the graph recomputes (the captured forward rebuilds the plan)
     value.mul_(0.5)
     gout.mul_(2.0)
     graph.replay()
@@ -702,6 +702,35 @@ def test_binned_backward_run_to_run(dtype):
         assert (first[0].float() - again[0].float()).abs().max().item() <= tol * scale
 
 
+@pytest.mark.parametrize("C", [16, 32, 64])
+def test_bf16_accumulate_single_terms_are_correctly_rounded(C):
+    """bf16 box attention sums grad_value on the matrix cores, with every weight split into two
+    bf16 terms (boxattn_binned_mfma.h).  One point per (query, head) on a map with one query:
+    every grad_value element is a single product w*a*g (or zero), so the stored value must be
+    that product rounded ONCE to bf16: within half a bf16 ulp (+2^-7 of slack for the 2^-17
+    split error).  With a one-term split the error would reach a whole ulp."""
+    rng = np.random.default_rng(1234 + C)
+    shapes = np.asarray([(9, 11)], dtype=np.int64)
+    B, H, Lq, P = 2, 8, 1, 1
+    S = int(shapes.prod(1).sum())
+    g = dict(shapes=shapes, lsi=np.zeros(1, dtype=np.int64),
+             value=rng.integers(-127, 128, (B, S, H, C)).astype(np.float64) / 64,
+             loc=rng.uniform(0.1, 0.9, (B, Lq, H, 1, P, 2)).astype(np.float32).astype(np.float64),
+             attn=rng.uniform(0.2, 1.0, (B, Lq, H, 1, P)).astype(np.float32).astype(np.float64),
+             grad_out=(rng.integers(1, 128, (B, Lq, H * C)) * rng.choice([-1, 1], (B, Lq, H * C))
+                       ).astype(np.float64) / 32)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])[0]
+    _, gv, _, _ = run_box(g, torch.bfloat16, "binned")
+    got = gv.double().cpu().numpy()
+    nz = want != 0
+    assert nz.sum() == B * H * 4 * C                       # four corners per point, all inside
+    assert (got[~nz] == 0).all()
+    half_ulp = 2.0 ** (np.floor(np.log2(np.abs(want[nz]))) - 8)
+    worst = (np.abs(got[nz] - want[nz]) / half_ulp).max()
+    assert worst <= 1.0 + 2.0 ** -7, "worst error %.4f half-ulps" % worst
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_forward_plan(dtype):
     """box_attn_forward_train bins the sample points for the backward while the forward kernel
@@ -729,6 +758,14 @@ def test_training_forward_plan(dtype):
                                  g2["grad_out"])
     gv2, _, _ = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)
     close(gv2, want2[0], dtype, "grad_value (stale plan ignored)")
+    # stale plan, weights this time (the bf16 flavour's records carry the attention weights)
+    _, plan3 = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
+    attn.mul_(0.5)
+    g3 = dict(g2, attn=(g["attn"].astype(np.float32) * np.float32(0.5)).astype(np.float64))
+    want3 = oc.box_attn_backward(g3["value"], g3["shapes"], g3["lsi"], g3["loc"], g3["attn"],
+                                 g3["grad_out"])
+    gv3, _, _ = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan3)
+    close(gv3, want3[0], dtype, "grad_value (plan with stale weights ignored)")
 
 
 def test_functions_use_the_plan_and_match():
