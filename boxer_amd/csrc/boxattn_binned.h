@@ -139,7 +139,10 @@ constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
 // WIDE records (bf16 box attention, boxattn_binned_mfma.h): {point id, x, y, attention weight}
 // instead of the id alone, so that the accumulate kernel reads everything but the upstream row
 // from its (coalesced) record stream instead of gathering two more 128-byte lines per record.
-template <int BW, int BH, bool FILL, bool WIDE = false>
+// PT = 4 (P % 4 == 0, 16-byte aligned tensors): a thread takes four consecutive points of one
+// (query, level) with two 16-byte loads and one level lookup (count pass 13.5 -> 11.7 us);
+// PT = 1: any P.
+template <int BW, int BH, bool FILL, bool WIDE, bool INTERLEAVE, int PT>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc,
                                                   const float *__restrict__ w_sp, BinPlan plan,
                                                   int H, int Lq, int P, int q_per_wg, int n_wg,
@@ -166,15 +169,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
 #endif
     const int b = s / H, h = s % H;
     const int LP = plan.L * P;
-    // Narrow records (VALU accumulate kernel): workgroup w takes the queries w, w + n_wg,
+    // INTERLEAVE (VALU accumulate kernel): workgroup w takes the queries w, w + n_wg,
     // w + 2 n_wg, ...: every workgroup's records are then a uniform sample of the map, and so is
     // any run of consecutive records of a bin.  That kernel works through a bin 64 records at a
     // time with one lane per destination pixel; with contiguous query ranges a round's records
     // came from neighbouring queries and piled up on a few pixels (longest per-pixel list 3.3x
     // the mean; interleaved 2.1x; accumulate kernel 133 -> 103 us).
-    // Wide records (MFMA accumulate kernel: a dense product, indifferent to the order): contiguous
-    // query ranges, whose records land in few bins, in runs -- 27 -> 24 us for the fill pass.
-    constexpr bool kInterleave = BOXATTN_TUNE_INTERLEAVE && !WIDE;
+    // MFMA accumulate kernel (a dense product, indifferent to the order): contiguous query
+    // ranges, whose records land in few bins, in runs -- 27 -> 24 us for the fill pass.
+    constexpr bool kInterleave = BOXATTN_TUNE_INTERLEAVE && INTERLEAVE;
     const int q0 = kInterleave ? wg : wg * q_per_wg, qstep = kInterleave ? n_wg : 1;
     const int n_q = kInterleave ? (q0 < Lq ? (Lq - q0 + qstep - 1) / qstep : 0)
                                 : max(0, min(q0 + q_per_wg, Lq) - q0);
@@ -192,47 +195,71 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     __syncthreads();
 
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    constexpr int U = 4;                          // points per thread per step (loads in flight)
+    static_assert(PT == 1 || PT == 4, "points per thread and step");
+    constexpr int U = PT == 4 ? 2 : 4;            // groups of PT points per thread per step (loads in flight)
     const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
     const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
-    const float rcp_lp = 1.0f / (float)LP, rcp_p = 1.0f / (float)P;
+    const int LPG = LP / PT, n_grp = n_q * LPG;               // groups per query, groups of this WG
+    const float rcp_lpg = 1.0f / (float)LPG, rcp_p = 1.0f / (float)P;
     int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
-    for (int i0 = threadIdx.x; i0 < n_pts; i0 += blockDim.x * U) {
-        float2 xy[U];
-        float wv[U];
-        int lp[U], ql[U];
+    (void)n_pts;
+    for (int g0 = threadIdx.x; g0 < n_grp; g0 += blockDim.x * U) {
+        float2 xy[U][PT];
+        float wv[U][PT];
+        int lp0[U], ql[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * (int)blockDim.x, n_pts - 1);
-            divmod_small(i, LP, rcp_lp, ql[u], lp[u]);
-            xy[u] = loc2[pid0 + ql[u] * qstride + lp[u]];
-            wv[u] = FILL && WIDE ? w_sp[pid0 + ql[u] * qstride + lp[u]] : 0.f;
+            const int g = min(g0 + u * (int)blockDim.x, n_grp - 1);
+            int lg;
+            divmod_small(g, LPG, rcp_lpg, ql[u], lg);
+            lp0[u] = lg * PT;
+            const size_t base = pid0 + ql[u] * qstride + lp0[u];
+            if constexpr (PT == 4) {
+                const float4 *p4 = reinterpret_cast<const float4 *>(loc2 + base);
+                const float4 a = p4[0], c = p4[1];
+                xy[u][0] = make_float2(a.x, a.y); xy[u][1] = make_float2(a.z, a.w);
+                xy[u][2] = make_float2(c.x, c.y); xy[u][3] = make_float2(c.z, c.w);
+                if constexpr (FILL && WIDE) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(w_sp + base);
+                    wv[u][0] = w4.x; wv[u][1] = w4.y; wv[u][2] = w4.z; wv[u][3] = w4.w;
+                }
+            } else {
+                xy[u][0] = loc2[base];
+                if constexpr (FILL && WIDE) wv[u][0] = w_sp[base];
+            }
+            if constexpr (!(FILL && WIDE)) {
+#pragma unroll
+                for (int k = 0; k < PT; ++k) wv[u][k] = 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (i0 + u * (int)blockDim.x >= n_pts) break;
-            const BinLevel lv = s_lv[(int)(((float)lp[u] + 0.5f) * rcp_p)];   // level = lp / P
-            int blk[4];
-            touched_blocks(xy[u].x, xy[u].y, lv, blk);
-            // predicated, not redirected to a dump slot: same-address LDS atomics serialise per
-            // lane, a shared dump slot made this kernel 1.6x slower
+            if (g0 + u * (int)blockDim.x >= n_grp) break;
+            const BinLevel lv = s_lv[(int)(((float)lp0[u] + 0.5f) * rcp_p)];   // level = lp / P
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (blk[j] >= 0) {
+            for (int k = 0; k < PT; ++k) {
+                int blk[4];
+                touched_blocks(xy[u][k].x, xy[u][k].y, lv, blk);
+                // predicated, not redirected to a dump slot: same-address LDS atomics serialise
+                // per lane, a shared dump slot made this kernel 1.6x slower
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (blk[j] >= 0) {
 #ifndef BOXATTN_TUNE_FILL_ABLATE
 #define BOXATTN_TUNE_FILL_ABLATE 0     // timing experiments only: 1 records into a 16 KiB window, 2 no record stores
 #endif
-                    int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
-                    if (BOXATTN_TUNE_FILL_ABLATE == 1) slot &= 1023;
-                    if (BOXATTN_TUNE_FILL_ABLATE == 2 && slot != -12345) continue;
-                    if constexpr (FILL) {
-                        const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | lp[u];
-                        if constexpr (WIDE)
-                            reinterpret_cast<int4 *>(rec)[slot] =
-                                make_int4(id, __float_as_int(xy[u].x), __float_as_int(xy[u].y),
-                                          __float_as_int(wv[u]));
-                        else
-                            rec[slot] = id;
+                        int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
+                        if (BOXATTN_TUNE_FILL_ABLATE == 1) slot &= 1023;
+                        if (BOXATTN_TUNE_FILL_ABLATE == 2 && slot != -12345) continue;
+                        if constexpr (FILL) {
+                            const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | (lp0[u] + k);
+                            if constexpr (WIDE)
+                                reinterpret_cast<int4 *>(rec)[slot] =
+                                    make_int4(id, __float_as_int(xy[u][k].x),
+                                              __float_as_int(xy[u][k].y), __float_as_int(wv[u][k]));
+                            else
+                                rec[slot] = id;
+                        }
                     }
                 }
             }
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
 #ifndef BOXATTN_TUNE_ACC_WPE
 #define BOXATTN_TUNE_ACC_WPE 1
 #endif
-template <typename ST, int C, bool INST, int RPL = 1>
+template <typename ST, int C, bool INST, int RPL = 1, bool WIDE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BOXATTN_TUNE_ACC_WPE)))
 void binned_accumulate_kernel(
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask,
@@ -462,7 +489,7 @@ void binned_accumulate_kernel(
         for (int k = 1; k < kMaxBinLevels; ++k)
             if (k == bg.level) lv = plan.lv[k];
         const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
-        const int *rec = records + (size_t)s * plan.rec_cap;   // item.y / .z index the slice
+        const int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);   // item.y / .z index the slice
         (void)offsets;
         f32x2 acc[CH / 2];                           // channel pairs (2i, 2i+1) of this half
 #pragma unroll
@@ -471,12 +498,25 @@ void binned_accumulate_kernel(
         // Software pipeline over rounds of R records: everything global that round r+1 needs
         // (record ids, locations, weights, upstream-gradient rows) is issued at the top of
         // round r and consumed one iteration later.  Inactive lanes use record 0 (valid).
-        struct Ids { int v[RPL]; };
+        // WIDE records {id, x, y, weight} (box attention): location and weight come with the
+        // coalesced record stream instead of two more gathers per record.
+        static_assert(!(WIDE && INST), "wide records carry one weight");
+        struct Ids { int v[RPL]; float2 xy[RPL]; float a[RPL]; };
         auto fetch_ids = [&](int rr) -> Ids {
             Ids r;
 #pragma unroll
-            for (int i = 0; i < RPL; ++i)
-                r.v[i] = (rr + i * 64 + lane < item.z) ? rec[rr + i * 64 + lane] : 0;
+            for (int i = 0; i < RPL; ++i) {
+                const bool have = rr + i * 64 + lane < item.z;
+                if constexpr (WIDE) {
+                    const int4 w = have ? reinterpret_cast<const int4 *>(rec)[rr + i * 64 + lane]
+                                        : make_int4(0, 0, 0, 0);
+                    r.v[i] = w.x;
+                    r.xy[i] = make_float2(__int_as_float(w.y), __int_as_float(w.z));
+                    r.a[i] = __int_as_float(w.w);
+                } else {
+                    r.v[i] = have ? rec[rr + i * 64 + lane] : 0;
+                }
+            }
             return r;
         };
         int row_n[RPL], mr_n[RPL];                     // rows of the round being fetched
@@ -487,8 +527,13 @@ void binned_accumulate_kernel(
                 const int q = r.v[i] >> plan.lp_bits, lp = r.v[i] & lp_mask;
                 row_n[i] = (int)(((size_t)b * Lq + q) * H + h);
                 const size_t pid = (size_t)row_n[i] * LP + lp;
-                xy[i] = loc2[pid];
-                as[i] = w_sp[pid];
+                if constexpr (WIDE) {
+                    xy[i] = r.xy[i];
+                    as[i] = r.a[i];
+                } else {
+                    xy[i] = loc2[pid];
+                    as[i] = w_sp[pid];
+                }
                 al[i] = INST ? w_lv[pid] : 0.f;
                 mr_n[i] = INST ? (int)((((size_t)b * Lq + q) * P + lp % P) * H + h) : 0;
             }

@@ -451,11 +451,22 @@ template <typename ST> inline bool side_stream_worth(const Dims &d)
 #ifndef BOXATTN_TUNE_ACC_MFMA
 #define BOXATTN_TUNE_ACC_MFMA 1    // bf16 box attention: the round's scatter-add as a dense MFMA product
 #endif
-// flavours whose accumulate step runs on the matrix cores from wide records (boxattn_binned_mfma.h)
-template <typename ST, bool INST> constexpr bool wide_records()
+#ifndef BOXATTN_TUNE_WIDE_F32
+#define BOXATTN_TUNE_WIDE_F32 0    // fp32 box attention (VALU accumulate kernel) from wide records: on uniformly random
+#endif                             // locations accumulate 154 -> 103 us, fill +17; on model-like ones only the +17
+// flavours whose accumulate step runs on the matrix cores (boxattn_binned_mfma.h)
+template <typename ST, bool INST> constexpr bool mfma_accumulate()
 {
     return BOXATTN_TUNE_ACC_MFMA && !INST && std::is_same<ST, bf16_t>::value;
 }
+// flavours whose bin passes write 16-byte records {id, x, y, weight}
+template <typename ST, bool INST> constexpr bool wide_records()
+{
+    return mfma_accumulate<ST, INST>() || (BOXATTN_TUNE_WIDE_F32 && !INST && sizeof(ST) == 4);
+}
+// the workspace query only knows the storage type: room for wide records whenever a flavour of
+// that type may write them
+constexpr bool wide_workspace(bool is_bf16) { return is_bf16 ? BOXATTN_TUNE_ACC_MFMA != 0 : BOXATTN_TUNE_WIDE_F32 != 0; }
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -551,7 +562,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
 
 // Binning passes (count, two scans, fill) of the binned backward into the workspace.  They only
 // read the sampling locations, so the training forward can run them ahead of the backward.
-template <bool WIDE>
+template <bool WIDE, bool INTERLEAVE>
 inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
                            const WsLayout &w, char *ws, hipStream_t st)
 {
@@ -564,15 +575,33 @@ inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, c
     const dim3 bgrid(w.n_wg, (ns + 7) / 8 * 8);      // the kernel maps workgroups to (slice, worker)
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
-    hipLaunchKernelGGL((bin_kernel<BW, BH, false, WIDE>), bgrid, dim3(kBinThreads), bsh, st, loc, w_sp,
-                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets, records);
+#ifndef BOXATTN_TUNE_BIN_PT
+#define BOXATTN_TUNE_BIN_PT 4
+#endif
+    // four points per thread where the layout allows 16-byte loads of a (query, level)'s points
+    const bool pt4 = BOXATTN_TUNE_BIN_PT == 4 && d.P % 4 == 0 && aligned(loc, 16) &&
+                     (!WIDE || aligned(w_sp, 16));
+    // (fill pass with 4-byte records: one point per thread -- neighbouring lanes then hold
+    // neighbouring slots and their stores coalesce: 18.9 us against 23.0 with four)
+#define BOXATTN_BIN(FILL_)                                                                         \
+    do {                                                                                           \
+        if (pt4 && (WIDE || !FILL_))                                                               \
+            hipLaunchKernelGGL((bin_kernel<BW, BH, FILL_, WIDE, INTERLEAVE, 4>), bgrid,            \
+                               dim3(kBinThreads), bsh, st, loc, w_sp, plan, d.H, d.Lq, d.P,        \
+                               w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
+        else                                                                                       \
+            hipLaunchKernelGGL((bin_kernel<BW, BH, FILL_, WIDE, INTERLEAVE, 1>), bgrid,            \
+                               dim3(kBinThreads), bsh, st, loc, w_sp, plan, d.H, d.Lq, d.P,        \
+                               w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
+    } while (0)
+    BOXATTN_BIN(false);
     hipLaunchKernelGGL(bin_scan_a_kernel,
                        dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
                        part, w.n_wg, subtot, plan);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items,
                        combos, n_items, plan);
-    hipLaunchKernelGGL((bin_kernel<BW, BH, true, WIDE>), bgrid, dim3(kBinThreads), bsh, st, loc, w_sp,
-                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets, records);
+    BOXATTN_BIN(true);
+#undef BOXATTN_BIN
 }
 
 template <typename ST, int G, bool INST>
@@ -591,7 +620,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // passes and the accumulate kernel.  Fork/join with events, so the caller still sees one
     // in-order stream (also valid under stream capture).
     SideStream side(st, side_stream_worth<ST>(d));
-    if (!plan_ready) launch_binning<wide_records<ST, INST>()>(loc, w_sp, d, plan, w, ws, st);
+    if (!plan_ready) launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, ws, st);
     {
         hipStream_t st = side.stream();                       // shadows: launch on the side stream
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
@@ -641,12 +670,13 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
 #define BOXATTN_TUNE_RPL_F32 1
 #endif
         constexpr int kRpl = INST ? 1 : (sizeof(ST) == 2 ? BOXATTN_TUNE_RPL_BF16 : BOXATTN_TUNE_RPL_F32);
-        if constexpr (wide_records<ST, INST>())
+        if constexpr (mfma_accumulate<ST, INST>())
             hipLaunchKernelGGL((binned_accumulate_mfma_kernel<4 * G>), dim3(wg_per_slice, ns8),
                                dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
                                records, grad_value, partials);
         else
-            hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl>), dim3(wg_per_slice, ns8),
+            hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl, wide_records<ST, INST>()>),
+                               dim3(wg_per_slice, ns8),
                                dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
                                d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
     }
@@ -676,7 +706,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   aligned(workspace, 256) && aligned(grad_value, 16);
     WsLayout w{};
     if (binned) {
-        w = ws_layout(d, plan, kBf16);
+        w = ws_layout(d, plan, wide_workspace(kBf16));
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
@@ -727,12 +757,12 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
               aligned(workspace, 256) && aligned(loc, 8);
     WsLayout w{};
     if (ok) {
-        w = ws_layout(d, plan, std::is_same<ST, bf16_t>::value);
+        w = ws_layout(d, plan, wide_workspace(std::is_same<ST, bf16_t>::value));
         ok = workspace_bytes >= w.total;
     }
     if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     SideStream side(st, side_stream_worth<ST>(d));
-    launch_binning<wide_records<ST, INST>()>(loc, w_sp, d, plan, w, (char *)workspace, side.stream());
+    launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
     side.join();
     if (rc == 0 && plan_built) *plan_built = 1;
@@ -797,7 +827,7 @@ size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int 
     const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
     BinPlan plan;
     if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
-    return std::max(fallback, ws_layout(d, plan, is_bf16 != 0).total);
+    return std::max(fallback, ws_layout(d, plan, wide_workspace(is_bf16 != 0)).total);
 }
 
 int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
