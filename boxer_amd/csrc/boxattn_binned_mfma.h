@@ -40,8 +40,8 @@
 namespace boxattn {
 
 #ifndef BOXATTN_TUNE_MFMA_ABLATE
-#define BOXATTN_TUNE_MFMA_ABLATE 0   // timing experiments only (wrong results): 1 no staging writes,
-#endif                               // 2 no row gathers, 3 no MFMA, 4 no weight scatter
+#define BOXATTN_TUNE_MFMA_ABLATE 0   // timing experiments only (wrong results), bit mask: 1 no staging
+#endif                               // writes, 2 no row gathers, 4 no MFMA, 8 no weight scatter, 16 rows gathered but not staged, 32 rows from a 4 KiB window
 typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -122,16 +122,27 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         // current round's operands have been read).  Idle lanes use query 0 (a valid, finite
         // row; their A columns stay zero).
         auto fetch_rec = [&](int rr) -> int4 {
-            return rr + lane < item.z ? rec[rr + lane] : make_int4(0, 0, 0, 0);
+#ifndef BOXATTN_TUNE_REC_NT
+#define BOXATTN_TUNE_REC_NT 0     // non-temporal record loads: 50.7 -> 52.7 us
+#endif
+            if (rr + lane >= item.z) return make_int4(0, 0, 0, 0);
+            if constexpr (BOXATTN_TUNE_REC_NT) {   // read once: keep the stream out of the way of the rows in L2
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(rec + rr + lane));
+                return make_int4(v.x, v.y, v.z, v.w);
+            } else {
+                return rec[rr + lane];
+            }
         };
         u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
         auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {
-            if (BOXATTN_TUNE_MFMA_ABLATE == 2) return;
+            if (BOXATTN_TUNE_MFMA_ABLATE & 2) return;
             const int row = (int)(((size_t)b * Lq + (r.x >> plan.lp_bits)) * H + h);
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
-                const int rj = __shfl(row, j, 64);
+                int rj = __shfl(row, j, 64);
+                if (BOXATTN_TUNE_MFMA_ABLATE & 32) rj = (rj & 63) + (int)((size_t)b * Lq * H);   // 64 hot rows
                 grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
             }
         };
@@ -140,7 +151,14 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         // piece) swap halves with DPP, and each writes whole dwords {G[j][c], G[j+1][c]}: the even
         // record's lane for the piece's even channels, the odd one's for the odd channels.
         auto stage_rows = [&]() {
-            if (BOXATTN_TUNE_MFMA_ABLATE == 1 || BOXATTN_TUNE_MFMA_ABLATE == 2) return;
+            if (BOXATTN_TUNE_MFMA_ABLATE & 3) return;
+            if (BOXATTN_TUNE_MFMA_ABLATE & 16) {    // rows gathered and waited for, not staged
+                unsigned x = 0;
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) x ^= grow[ps][0] ^ grow[ps][1] ^ grow[ps][2] ^ grow[ps][3];
+                if (x == 0x12345678u) gt[lane] = (unsigned short)x;
+                return;
+            }
             const int odd = (lane / LPR) & 1;
             const unsigned sel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selectors
 #pragma unroll
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = whi[k];
+                if (slot[k] >= 0 && !(BOXATTN_TUNE_MFMA_ABLATE & 8)) at[slot[k]] = whi[k];
             wave_lds_sync();
             // ---- the product: 4 K-steps of 16 records per 32-channel block, hi term then lo term
             mfma_bf16x8 g[R / 16][NCB];
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                     const u32x2 *gp = reinterpret_cast<const u32x2 *>(&gt[(cb * 32 + col) * GS + k0]);
                     const u32x2 g0 = gp[0], g1 = gp[1];
                     g[t][cb] = __builtin_bit_cast(mfma_bf16x8, u32x4{g0.x, g0.y, g1.x, g1.y});
-                    if (BOXATTN_TUNE_MFMA_ABLATE != 3)
+                    if (!(BOXATTN_TUNE_MFMA_ABLATE & 4))
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_hi, acc[cb], 0, 0, 0);
                     else
                         acc[cb][0] += __builtin_bit_cast(u32x4, g[t][cb])[0] + __builtin_bit_cast(u32x4, p_hi)[1];
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             wave_lds_sync();                         // a wave's LDS operations execute in order
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = wlo[k];
+                if (slot[k] >= 0 && !(BOXATTN_TUNE_MFMA_ABLATE & 8)) at[slot[k]] = wlo[k];
             wave_lds_sync();
 #pragma unroll
             for (int t = 0; t < R / 16; ++t) {
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                     mfma_bf16x8, *reinterpret_cast<const u32x4 *>(&at[col * AS + k0]));
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
-                    if (BOXATTN_TUNE_MFMA_ABLATE != 3)
+                    if (!(BOXATTN_TUNE_MFMA_ABLATE & 4))
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_lo, acc[cb], 0, 0, 0);
                     else
                         acc[cb][1] += __builtin_bit_cast(u32x4, p_lo)[2];
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             // ---- clear this round's weights, stage the next round's rows (they have arrived)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (slot[k] >= 0 && BOXATTN_TUNE_MFMA_ABLATE != 4) at[slot[k]] = 0;
+                if (slot[k] >= 0 && !(BOXATTN_TUNE_MFMA_ABLATE & 8)) at[slot[k]] = 0;
             if (more) {
                 stage_rows();
 #pragma unroll
