@@ -133,9 +133,6 @@ __device__ __forceinline__ void touched_blocks(float x, float y, const BinLevel 
 #define BOXATTN_TUNE_BIN_THREADS 512
 #endif
 constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
-#ifndef BOXATTN_TUNE_BIN_XCD
-#define BOXATTN_TUNE_BIN_XCD 0     // all workgroups of a slice on one XCD: no gain measured (either record width)
-#endif
 // WIDE records (bf16 box attention, boxattn_binned_mfma.h): {point id, x, y, attention weight}
 // instead of the id alone, so that the accumulate kernel reads everything but the upstream row
 // from its (coalesced) record stream instead of gathering two more 128-byte lines per record.
@@ -157,16 +154,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     // ~200 k single-lane atomics on 226 cache lines), and the record order is deterministic.
     extern __shared__ int sh_bins[];
     int *hist = sh_bins;
-    // grid = (n_wg, slices rounded up to 8)
-#if BOXATTN_TUNE_BIN_XCD
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    const int per_xcd = (plan.n_slices + 7) / 8;
-    const int s = bid % 8 + 8 * ((bid / 8) % per_xcd), wg = (bid / 8) / per_xcd;
-    if (s >= plan.n_slices || wg >= n_wg) return;
-#else
+    // grid = (n_wg, slices).  (Placing all workgroups of a slice on one XCD, so that the record
+    // writes of a bin merge in one L2, changed nothing: the fill pass is bound by the bytes.)
     const int s = blockIdx.y, wg = blockIdx.x;
-    if (s >= plan.n_slices) return;
-#endif
     const int b = s / H, h = s % H;
     const int LP = plan.L * P;
     // INTERLEAVE (VALU accumulate kernel): workgroup w takes the queries w, w + n_wg,

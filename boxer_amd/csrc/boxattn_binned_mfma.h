@@ -117,22 +117,13 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 
-        // software pipeline over rounds of 64 records: the records are read two rounds ahead,
-        // their upstream-gradient rows one round ahead (into registers; staged into LDS once the
-        // current round's operands have been read).  Idle lanes use query 0 (a valid, finite
+        // software pipeline over rounds of 64 records: the records are read three rounds ahead,
+        // their upstream-gradient rows two (into registers; staged into LDS once the current
+        // round's operands have been read).  Idle lanes use query 0 (a valid, finite
         // row; their A columns stay zero).
         auto fetch_rec = [&](int rr) -> int4 {
-#ifndef BOXATTN_TUNE_REC_NT
-#define BOXATTN_TUNE_REC_NT 0     // non-temporal record loads: 50.7 -> 52.7 us
-#endif
-            if (rr + lane >= item.z) return make_int4(0, 0, 0, 0);
-            if constexpr (BOXATTN_TUNE_REC_NT) {   // read once: keep the stream out of the way of the rows in L2
-                typedef int i32x4 __attribute__((ext_vector_type(4)));
-                const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(rec + rr + lane));
-                return make_int4(v.x, v.y, v.z, v.w);
-            } else {
-                return rec[rr + lane];
-            }
+            // (a non-temporal load here, to keep the stream out of the rows' way in L2: 50.7 -> 52.7 us)
+            return rr + lane < item.z ? rec[rr + lane] : make_int4(0, 0, 0, 0);
         };
         u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
         auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {

@@ -572,7 +572,7 @@ inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, c
     int *n_items = (int *)(ws + w.n_items);      // every scratch word is written before it is read
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
-    const dim3 bgrid(w.n_wg, (ns + 7) / 8 * 8);      // the kernel maps workgroups to (slice, worker)
+    const dim3 bgrid(w.n_wg, ns);
     const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
 #ifndef BOXATTN_TUNE_BIN_PT

@@ -172,14 +172,6 @@ __device__ __forceinline__ void divmod_magic(unsigned n, unsigned d, unsigned ma
     r = n - q * d;
     if (r >= d) { ++q; r -= d; }
 }
-// level of flattened point index lp = l * P + p: a compare chain instead of a division
-__device__ __forceinline__ int level_of(int lp, int P, int L) {
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) l += (k < L && lp >= k * P) ? 1 : 0;
-    return l;
-}
-
 // ---------------------------------------------------------------------------------------
 // cross-lane sums
 // ---------------------------------------------------------------------------------------
