@@ -631,14 +631,35 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
             const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
                                                     (!INST || aligned(grad_mask, 16)));
             const int blocks = gather_blocks(d, ix, kWave / cfg.G);
-            const int split = point_split(blocks, (d.L * d.P + cfg.G - 1) / cfg.G);
+            // few pairs x many points (instance attention on the mask-decoder grid): one wave
+            // per pair, its lane groups over the point tiles; else one lane group per pair
+#ifndef BOXATTN_TUNE_PG_WAVE_PER_PAIR
+#define BOXATTN_TUNE_PG_WAVE_PER_PAIR 1
+#endif
+            const int tiles = (d.L * d.P + cfg.G - 1) / cfg.G;
+            const bool wpp = BOXATTN_TUNE_PG_WAVE_PER_PAIR && INST && g_variant != 5 &&
+                             blocks < 1024 && tiles >= kWave / cfg.G;
+            if (wpp) {
+                const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
+                                                : ceil_div_sz(n_qh, 4);
+                const int split = point_split(wblocks, tiles / (kWave / cfg.G));
+#define BOXATTN_PG2W(GG, VV)                                                                         \
+    hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
+                       dim3(wblocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
+                       grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
+                       ix, (unsigned)vbytes);
+                BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
+#undef BOXATTN_PG2W
+            } else {
+                const int split = point_split(blocks, tiles);
 #define BOXATTN_PG2(GG, VV)                                                                   \
     hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
                        dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
                        w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
                        grad_lv, ix, (unsigned)vbytes);
-            BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
+                BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
 #undef BOXATTN_PG2
+            }
         } else {
             const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
             hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),

@@ -578,7 +578,11 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
 // ---------------------------------------------------------------------------------------
 // backward, point gradients only (grad_loc, grad_weight[s]); grad_value is boxattn_binned.h
 // ---------------------------------------------------------------------------------------
-template <typename ST, int G, bool INST, int U, int VEC>
+// WP ("wave per pair"; few pairs x many points, e.g. the 14x14 mask-decoder grid of instance
+// attention): all lane groups of a wave work on ONE (query, head) pair, group g on the point
+// tiles g, g + 16, ...: the wave's results are 64 consecutive points (whole lines instead of
+// 16- and 32-byte pieces 3 KiB apart) and its location / weight reads are contiguous.
+template <typename ST, int G, bool INST, int U, int VEC, bool WP = false>
 __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -606,7 +610,16 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);
     bool active;
-    const unsigned qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
+    unsigned qh;
+    if constexpr (WP) {
+        qh = blockIdx.x * (blockDim.x / kWave) + wv;                      // one pair per wave
+        if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
+            qh = ((blockIdx.x / 8) * (blockDim.x / kWave) + wv) * (unsigned)H + blockIdx.x % 8;
+        active = qh < ix.n_qh;
+        qh = active ? qh : ix.n_qh - 1;
+    } else {
+        qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
+    }
     const int slot = lane % G;
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
@@ -624,26 +637,30 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     RowT g;
     row_load<ST, VEC, PSB>(grad_out + (size_t)qh * C + slot * LCH, g);
 
-    // gridDim.y workgroups share the point tiles of a pair (few queries x many points)
+    // gridDim.y workgroups share the point tiles of a pair (few queries x many points).
+    // t_step: distance between two tiles of a lane group (WP: the groups interleave)
     const int tiles = (LP + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int t_begin = (int)blockIdx.y * tps * G, t_end = min(LP, t_begin + tps * G);
+    const int t_first = (int)blockIdx.y * tps * G, t_end = min(LP, t_first + tps * G);
+    const int t_begin = t_first + (WP ? (lane / G) * G : 0);
+    constexpr int t_step = WP ? PAIRS * G : G;
     float2 xy_n = loc2[pt0 + min(t_begin + slot, LP - 1)];      // first tile
     float as_n = w_sp[pt0 + min(t_begin + slot, LP - 1)];
     float al_n = INST ? w_lv[pt0 + min(t_begin + slot, LP - 1)] : 0.f;
-    const bool buffered = kCanBuffer && gridDim.y == 1 && (LP == 16 || LP == 8) &&
+    const bool buffered = kCanBuffer && !WP && gridDim.y == 1 && (LP == 16 || LP == 8) &&
                           ((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0;
     float *res = res_all + (kCanBuffer ? (wv * PAIRS + lane / G) * (kBufLP * 3) : 0);
-    for (int t0 = t_begin; t0 < t_end; t0 += G) {
+    // (wave-uniform trip count: with WP the groups whose tile lies past the end idle)
+    for (int tu = t_first, t0 = t_begin; tu < t_end; tu += t_step, t0 += t_step) {
         // ---- step A (the lane keeps its point's geometry in registers for the finish)
         const int lp = t0 + slot;
-        const bool have = lp < LP;
+        const bool have = lp < t_end;
         const int lq = have ? lp : LP - 1;
         const int l = (int)(((float)lq + 0.5f) * rcp_p);           // lq / P (exact, see rcp_p)
         float2 xy;
         float as, al;
         if constexpr (kGatherPrefetch) {
             xy = xy_n; as = as_n; al = al_n;
-            const int nq = min(lp + G, LP - 1);
+            const int nq = min(lp + t_step, LP - 1);
             xy_n = loc2[pt0 + nq];
             as_n = w_sp[pt0 + nq];
             al_n = INST ? w_lv[pt0 + nq] : 0.f;
