@@ -440,14 +440,13 @@ struct SideStream {
 #define BOXATTN_TUNE_CHUNK 1024
 #endif
 constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item
-constexpr size_t kSideStreamMinPoints = 1u << 20;   // below this the fork/join costs more than it hides
-// Two streams pay for fp32 storage (C2: 283 -> 270 us per step) and not for bf16 (229 -> 234 us):
-// every cross-stream dependency costs ~20 us of event latency and the kernels mostly contend
-// for the same CUs (rocprofv3 timelines).
-template <typename ST> inline bool side_stream_worth(const Dims &d)
-{
-    return sizeof(ST) == 4 && d.n_qh() * d.L * d.P >= kSideStreamMinPoints;
-}
+// One stream by default.  Running the point-gradient kernel (and, in the training forward, the
+// bin passes) on the library's helper stream once paid for fp32 storage (C2: 283 -> 270 us per
+// step); with the faster bin passes it no longer does (C2 fp32 278 us on one stream, 283 on
+// two; C5' 932 / 928; bf16 192 / 208): every cross-stream dependency costs ~20 us of event
+// latency and the kernels mostly contend for the same CUs (rocprofv3 timelines).
+// boxattn_set_variant(6) still forks.
+template <typename ST> inline bool side_stream_worth(const Dims &) { return false; }
 #ifndef BOXATTN_TUNE_ACC_MFMA
 #define BOXATTN_TUNE_ACC_MFMA 1    // bf16 box attention: the round's scatter-add as a dense MFMA product
 #endif

@@ -126,10 +126,10 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * plan_ready: 0 = the call bins the sample points itself; 1 = `workspace` already holds the plan
  * that a *_fwd_train_* call built for the SAME sampling locations and dimensions (the call then
  * fails with hipErrorInvalidValue if the binned algorithm does not apply).
- * The binned path uses no float atomics and no zero-fill; it runs its point-gradient kernel on
- * a library-owned low-priority helper stream (one per device, created on first use) that is
- * forked from and joined back into `stream` with events, so the caller still sees one in-order
- * stream (valid under stream capture).
+ * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`; with
+ * boxattn_set_variant(6) the point-gradient kernel runs on a library-owned low-priority helper
+ * stream (one per device, created on first use) that is forked from and joined back into
+ * `stream` with events, so the caller still sees one in-order stream (valid under capture).
  */
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                                    const int64_t *shapes_host, const int64_t *lsi_host);
@@ -191,8 +191,9 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
 /*
  * ---- training forward: forward + backward plan ----------------------------------------------
  * Same as the plain forward, and additionally (when the binned backward applies) runs the
- * binning passes of the backward -- they only depend on the sampling locations -- on the
- * library's helper stream, concurrently with the forward kernel, into `workspace`
+ * binning passes of the backward -- they only depend on the sampling locations and, for the
+ * bf16 box flavour, whose 16-byte records carry them, the attention weights -- ahead of the
+ * forward kernel (variant 6: on the library's helper stream, next to it) into `workspace`
  * (boxattn_bwd_workspace_bytes bytes; it must stay untouched until the matching *_bwd_ws_*
  * call, which is then given plan_ready = 1).  *plan_built is set to 1 if the plan was built,
  * 0 if the call was just a plain forward (shape not eligible / workspace too small).
@@ -228,8 +229,9 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
  *   4 = like 0 but everything runs on the caller's stream (no helper stream),
  *   5 = like 0 but the instance forward with few (query, head) pairs keeps the workgroup
  *       split of the points instead of the one-wave-per-pair kernel.
- *   6 = like 0 but the helper stream is always used (point gradients next to binning /
- *       accumulate, binning next to the training forward).  0 picks 4 or 6 per storage type.
+ *   6 = like 0 but the helper stream is used (point gradients next to binning / accumulate,
+ *       binning next to the training forward).  0 behaves like 4: measured faster for both
+ *       storage types.
  * Returns the previous value.
  */
 int boxattn_set_variant(int variant);
