@@ -234,9 +234,9 @@ def kernel_profile(step, steps, variant):
     """Average duration of the op's main kernels, measured with HIP events that the library
     records around them on the launch stream (boxattn_profile_*; see include/boxattn.h).
 
-    Same schedule as the timed region (for bf16 that is the one-stream schedule; for fp32 the
-    library overlaps the point-gradient kernel with binning / accumulate on its helper stream,
-    which stretches the overlapped kernels -- `--variant 4` gives their stand-alone times)."""
+    Same schedule as the timed region: one stream, so a kernel's duration is its own
+    (`--variant 6` forks the point-gradient kernel onto the library's helper stream, which
+    stretches the overlapped kernels)."""
     from boxer_amd import _lib
     if not hasattr(_lib, "profile_begin"):
         return None
