@@ -20,14 +20,25 @@ Multi-GPU: the path shards over images with no data-path collective (SURVEY.md 8
 rank processes its own B images; value = total points of all ranks / max-over-ranks time
 ("scaling": "weak").  The only collectives are the timing barrier and the MAX reduction.
 
+``python bench.py --gpus N`` with N > 1 and no launcher environment starts its own N ranks
+(one fresh ``python`` child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
+the parent touches the GPU; the counterpart of the reference's tools/run.py:59-75); under
+``python -m torch.distributed.run`` it uses the ranks it is given.  Backend "nccl" (= RCCL).
+
+Before anything is timed the step's tensors are compared with the CPU oracle (``--no-check``
+skips it); a failing comparison prints no JSON line and exits non-zero.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-"roofline" (dominant kernel vs the 8 TB/s HBM peak) and "cpu_baseline" (the pure-PyTorch
-grid_sample formulation timed on the host cores; rank 0, N=1 only).
+"roofline" (dominant kernel vs the 8 TB/s HBM peak) and "cpu_baseline" (the C restatement of
+the reference kernels on the bench workload -- kind "port" -- plus, inside it, the north star's
+"pure-PyTorch fallback" leg at BASELINE configs[0] (C1); rank 0, N=1 only).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,6 +52,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # name: (levels, Lq ("S" = one query per pixel), points per level P, kind)
 WORKLOADS = {
+    # BASELINE.json configs[0]: the pure-PyTorch CPU path's shape (1 level 64x64, 100 queries, B = 1)
+    "C1": ([(64, 64)], 100, 4, "box"),
     "C2": ([(100, 100), (50, 50), (25, 25), (13, 13)], "S", 4, "box"),
     "C2p": ([(100, 167), (50, 84), (25, 42), (13, 21)], "S", 4, "box"),
     "C3": ([(100, 100), (50, 50), (25, 25), (13, 13)], 300, 16, "instance"),
@@ -52,6 +65,7 @@ WORKLOADS = {
 }
 H_HEADS, C_HEAD, BATCH = 8, 32, 2
 PREHEAT_STEPS = 100         # untimed steps (warm-up included) before the timed region, at least
+PREHEAT_SECONDS = 1.0       # ... and at least this long (clock ramp; makes the run visible to samplers)
 
 
 # --------------------------------------------------------------------------------------
@@ -253,19 +267,72 @@ def kernel_profile(step, steps, variant):
 
 
 # --------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N = 1): the pure-PyTorch grid_sample formulation on the host cores
+# parity gate: nothing is timed unless the step's tensors match the CPU oracle
 # --------------------------------------------------------------------------------------
-def cpu_baseline(workload, budget_s=20.0):
-    """The CPU restatement of the reference kernels (oracle/boxattn_oracle.c: OpenMP over
-    (image, head), fp32) timed on the host cores, forward + backward, on the bench workload
-    itself (B = 2 images; the loop is bounded to ~budget_s seconds).  It is the faster of the two
-    CPU formulations the repository has: the reference's own pure-PyTorch grid_sample fallback
-    (oracle/torch_fallback.py) runs C2 at 0.00016 Gpts/s on 256 threads, this one two orders of
-    magnitude faster on 16."""
+def parity_gate(inp, step):
+    """Run ``step`` once and compare every tensor it returns with the CPU oracle
+    (oracle/boxattn_oracle.c, fp64, on the same -- for bf16: the rounded -- inputs).
+    -> None when everything matches, else a description of the first failure.
+
+    Bound per element: |got - want| <= tol * (max(1, rms(want)) + |want|), tol = 1e-4 for fp32
+    tensors and 1e-2 for bf16 ones (BASELINE.json north_star); grad_loc is not compared for
+    points within 1e-4 px of a bilinear cell edge (it is discontinuous there)."""
+    import numpy as np
+    from oracle import boxattn_oracle as oc
+    out, grads = step()
+    torch.cuda.synchronize()
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    a = {k: (f64(v) if v.is_floating_point() else v.cpu().numpy())
+         for k, v in inp.items() if isinstance(v, torch.Tensor)}
+    oc.set_num_threads(max(1, min(os.cpu_count() or 1, inp["dims"]["B"] * inp["dims"]["H"])))
+    if inp["kind"] == "box":
+        want = [oc.box_attn_forward(a["value"], a["shapes"], a["lsi"], a["loc"], a["attn"])]
+        want += list(oc.box_attn_backward(a["value"], a["shapes"], a["lsi"], a["loc"], a["attn"],
+                                          a["grad_out"]))
+        got = [out] + list(grads)
+        names = ["out", "grad_value", "grad_loc", "grad_attn"]
+    else:
+        want = list(oc.instance_attn_forward(a["value"], a["shapes"], a["lsi"], a["loc"],
+                                             a["attn"], a["level_w"]))
+        want += list(oc.instance_attn_backward(a["value"], a["shapes"], a["lsi"], a["loc"],
+                                               a["attn"], a["level_w"], a["grad_out"],
+                                               a["grad_mask"]))
+        got = list(out) + list(grads)
+        names = ["out", "mask_out", "grad_value", "grad_loc", "grad_spatial", "grad_level"]
+    size = a["shapes"].astype(np.float64)[None, None, None, :, None, ::-1]       # (W, H)
+    pix = a["loc"] * size - 0.5
+    edge = (np.abs(pix - np.round(pix)) < 1e-4).any(-1, keepdims=True)
+    for name, g, w in zip(names, got, want):
+        tol = 1e-2 if g.dtype == torch.bfloat16 else 1e-4
+        g = f64(g).reshape(w.shape)
+        if name == "grad_loc":
+            g, w = g * ~edge, w * ~edge
+        if not np.isfinite(g).all():
+            return "%s: non-finite values" % name
+        scale = max(1.0, float(np.sqrt(np.mean(w * w)))) if w.size else 1.0
+        ratio = np.abs(g - w) / (scale + np.abs(w))
+        if w.size and float(ratio.max()) > tol:
+            return "%s: worst |err| / (%.3g + |want|) = %.3e > %.0e" % (
+                name, scale, float(ratio.max()), tol)
+    return None
+
+
+# --------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1), both bounded
+# --------------------------------------------------------------------------------------
+def cpu_baseline(workload, budget_s=15.0):
+    """Leg 1 (the line's ``cpu_baseline``, kind "port"): the C restatement of the reference
+    kernels (oracle/boxattn_oracle.c, OpenMP over image x head, fp32) on the bench workload
+    itself, forward + backward, ~budget_s seconds.
+    Leg 2 (``pytorch_fallback`` inside it): BASELINE.json's north-star wording -- the repo's
+    pure-PyTorch formulation (oracle/torch_fallback.py: per level grid_sample + weighted sum,
+    autograd backward; the counterpart of the reference's tests/box_attn_test.py:9-42) on the
+    host cores at BASELINE configs[0] (C1), core count stated."""
     from oracle import boxattn_oracle as oc
     levels, lq, P, kind = WORKLOADS[workload]
     kind = "box" if kind.startswith("box3d") else kind
-    inp = make_inputs(workload, torch.float32, "cpu", family="model", batch=BATCH, seed=0)
+    batch = 1 if workload == "C1" else BATCH
+    inp = make_inputs(workload, torch.float32, "cpu", family="model", batch=batch, seed=0)
     a = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
     np_ = n_points(inp["dims"])
     pairs = inp["dims"]["B"] * inp["dims"]["H"]               # the restatement's parallel axis
@@ -291,12 +358,48 @@ def cpu_baseline(workload, budget_s=20.0):
     for _ in range(iters):
         once()
     dt = (time.perf_counter() - t0) / iters
+    res = {"value": np_ / dt / 1e9, "unit": "Gsample-points/s", "cores": cores,
+           "kind": "port",
+           "sample": "%s fp32, B=%d images (%d points), fwd+bwd of the C restatement of the "
+                     "reference kernels (oracle/boxattn_oracle.c), %d iterations, %.3f s/iter, "
+                     "%d OpenMP threads (one per image x head)" % (workload, batch, np_, iters,
+                                                                   dt, cores)}
+    res["pytorch_fallback"] = pytorch_fallback_c1()
+    return res
+
+
+def pytorch_fallback_c1(budget_s=8.0):
+    """BASELINE.json configs[0]: box attention as pure PyTorch on the CPU (grid_sample
+    formulation, fwd + autograd bwd), N=1, 1 level 64x64, 100 queries, 8 heads, 2x2 grid."""
+    from oracle import torch_fallback as tf
+    inp = make_inputs("C1", torch.float32, "cpu", family="model", batch=1, seed=0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    v = inp["value"].clone().requires_grad_()
+    loc = inp["loc"].clone().requires_grad_()
+    attn = inp["attn"].clone().requires_grad_()
+    shapes = [tuple(int(x) for x in r) for r in inp["shapes"]]
+
+    def once():
+        out = tf.box_attn(v, shapes, loc, attn)
+        v.grad = loc.grad = attn.grad = None
+        out.backward(inp["grad_out"])
+
+    once()
+    t0 = time.perf_counter()
+    once()
+    first = time.perf_counter() - t0
+    iters = max(3, min(2000, int(budget_s / max(first, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    dt = (time.perf_counter() - t0) / iters
+    np_ = n_points(inp["dims"])
     return {"value": np_ / dt / 1e9, "unit": "Gsample-points/s", "cores": cores,
-            "kind": "port",
-            "sample": "%s fp32, B=%d images (%d points), fwd+bwd of the C restatement of the "
-                      "reference kernels (oracle/boxattn_oracle.c), %d iterations, %.2f s/iter, "
-                      "%d OpenMP threads (one per image x head)" % (workload, BATCH, np_, iters,
-                                                                    dt, cores)}
+            "kind": "pure-PyTorch grid_sample formulation (oracle/torch_fallback.py)",
+            "sample": "C1 fp32: B=1, 1 level 64x64, 100 queries, 8 heads, C=32, 2x2 grid (%d "
+                      "points), fwd + autograd bwd, %d iterations, %.3f ms/iter, torch threads=%d"
+                      % (np_, iters, dt * 1e3, cores)}
 
 
 # --------------------------------------------------------------------------------------
@@ -332,22 +435,52 @@ def throughput(elapsed, points_per_rank_step, world, steps):
     return total / elapsed / 1e9, elapsed / steps * 1e3
 
 
+
 # --------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N without a launcher
+# --------------------------------------------------------------------------------------
+def spawn_ranks(n, cmd=None):
+    """Start n fresh ``python bench.py`` children (one per GPU) with the launcher environment
+    set, BEFORE this process has touched the GPU (no re-exec of a GPU process: plain children);
+    rank 0's stdout is ours.  Returns the exit code.  (``cmd``: another command line, for the
+    CPU test of the launcher.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=5000)        # ~0.5-1 s timed at the default workload
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--inputs", default="model", choices=["model", "test"])
-    ap.add_argument("--batch", type=int, default=BATCH,
-                    help="images per GPU (the headline line uses the default)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU (the headline line uses the default: 2; C1: 1)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a HIP graph and time replays (not the headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity gate")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1 if args.workload == "C1" else BATCH
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -371,20 +504,46 @@ def main():
                       seed=rank)
     step = make_step(inp)
     eager_step = step
+
+    # parity gate on the tensors of the step that is about to be timed (every rank its own)
+    if not args.no_check:
+        failure = parity_gate(inp, step)
+        if failure is not None:
+            print("bench.py: parity gate FAILED on rank %d (%s %s %s): %s" % (
+                rank, args.workload, args.dtype, args.inputs, failure), file=sys.stderr, flush=True)
+            sys.exit(3)
     if args.graph:
         step = graph_step(step)
 
     # Device pre-heat: the first ~100 steps after start-up run up to ~8 % slower than the steady state
     # (clock ramp, tools/gpu_ramp.py).  With a short --warmup the gap is filled here, outside
     # the W warm-up + K timed steps of the protocol, so that the number is the steady-state one.
-    preheat = max(0, PREHEAT_STEPS - args.warmup)
-    for _ in range(preheat):
+    preheat, t0 = 0, time.perf_counter()
+    while preheat < max(0, PREHEAT_STEPS - args.warmup) or \
+            time.perf_counter() - t0 < PREHEAT_SECONDS:
         step()
+        preheat += 1
+        if preheat % 64 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     elapsed = run_timed(step, args.steps, args.warmup, torch.cuda.synchronize, dist, device)
     step = eager_step                      # the per-kernel profile needs the launches themselves
 
     np_rank = n_points(inp["dims"])
     value, ms_per_step = throughput(elapsed, np_rank, world, args.steps)
+    per_rank = None
+    if dist is not None:                   # per-rank spread (clock / power variance between GPUs)
+        t0 = time.perf_counter()           # every rank alone, no barrier: its own rate
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        mine = torch.tensor([np_rank * args.steps / (time.perf_counter() - t0) / 1e9],
+                            device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        vals = sorted(float(t.item()) for t in allr)
+        per_rank = {"min": round(vals[0], 3), "median": round(vals[len(vals) // 2], 3),
+                    "max": round(vals[-1], 3), "unit": "Gsample-points/s per GPU (each rank re-timed alone, no barrier)"}
 
     phases = time_phases(inp)
     prof = kernel_profile(step, min(args.steps, 20), args.variant)
@@ -395,7 +554,7 @@ def main():
         # dominant kernel = the longest of the op's kernels (HIP events recorded by the library
         # around each launch, on the launch stream)
         kern = {k: v for k, v in (prof or {}).items() if v["ms"]}
-        if kern:
+        if kern and any(k in b_kernel for k in kern):
             dom = max((k for k in kern if k in b_kernel), key=lambda k: kern[k]["ms"])
             dom_ms, dom_bytes = kern[dom]["ms"], b_kernel[dom]
             src = ("HIP events around every launch of the kernel (boxattn_profile_*), same "
@@ -405,16 +564,20 @@ def main():
             src = "HIP events around the backward call"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         step_gbs = (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             with open(tfile) as fh:
                 t = json.load(fh)
             key = "%s/%s/%s" % (args.workload, args.dtype, args.inputs)
             traffic = t.get(key, {}).get(dom)
+            if traffic is not None:
+                traffic_src = ("profiles/hbm_traffic.json (builder's rocprofv3 --pmc run of this "
+                               "command, %s; not measured in this run)" % t.get("_round", "r02"))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": dom_bytes,
                     "avg_launch_ms": round(dom_ms, 4), "timing": src,
                     "fwd_bwd": {"algorithmic_bytes": b_fwd + b_bwd,
                                 "achieved_GBs": round(step_gbs, 1),
@@ -437,9 +600,12 @@ def main():
                                        inp["dims"]["Lq"], H_HEADS, C_HEAD, inp["dims"]["P"], args.batch,
                                        args.inputs),
                        "points_per_step_per_gpu": np_rank, "parallelism": "dp%d" % world,
-                       "preheat_steps": preheat},
+                       "preheat_steps": preheat,
+                       "parity_gate": "skipped" if args.no_check else "passed (all tensors vs CPU oracle)"},
             "roofline": roofline,
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)

@@ -13,8 +13,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_NAME = "libboxattn_hip.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
 SOURCES = ["boxattn_capi.hip"]
-HEADERS = ["boxattn_device.h", "boxattn_generic.h", "boxattn_fast.h", "boxattn_binned.h",
-           "boxattn_gather2.h", "boxattn_grid.h"]
+HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-shared", "-Wall", "-Wno-pass-failed"]
 
@@ -49,7 +48,7 @@ EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def hipcc_path():
@@ -138,13 +137,13 @@ def profile_begin():
     load().boxattn_profile_begin()
 
 
-PROFILE_SLOTS = ("fwd", "bwd_points", "bwd_accumulate", "bwd_binning")
+PROFILE_SLOTS = ("fwd", "bwd_points", "bwd_accumulate", "bwd_binning", "bwd_combine", "bwd_prep")
 
 
 def profile_end():
-    """-> {slot: {"ms": average kernel duration, "launches": n}} for the four timing slots."""
-    ms = (ctypes.c_double * 4)()
-    n = (ctypes.c_int * 4)()
+    """-> {slot: {"ms": average kernel duration, "launches": n}} for the timing slots."""
+    ms = (ctypes.c_double * len(PROFILE_SLOTS))()
+    n = (ctypes.c_int * len(PROFILE_SLOTS))()
     load().boxattn_profile_end(ms, n)
     return {name: {"ms": (ms[i] / n[i] if n[i] else None), "launches": int(n[i])}
             for i, name in enumerate(PROFILE_SLOTS)}

@@ -119,22 +119,27 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
 
         // software pipeline over rounds of 64 records: the records are read three rounds ahead,
         // their upstream-gradient rows two (into registers; staged into LDS once the current
-        // round's operands have been read).  Idle lanes use query 0 (a valid, finite
-        // row; their A columns stay zero).
+        // round's operands have been read).  Idle lanes stage a zero row (and their
+        // A columns stay zero).
         auto fetch_rec = [&](int rr) -> int4 {
             // (a non-temporal load here, to keep the stream out of the rows' way in L2: 50.7 -> 52.7 us)
-            return rr + lane < item.z ? rec[rr + lane] : make_int4(0, 0, 0, 0);
+            return rr + lane < item.z ? rec[rr + lane] : make_int4(-1, 0, 0, 0);   // id -1: idle lane
         };
         u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
         auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {
             if (BOXATTN_TUNE_MFMA_ABLATE & 2) return;
-            const int row = (int)(((size_t)b * Lq + (r.x >> plan.lp_bits)) * H + h);
+            // idle lanes (past the item's last record) contribute a ZERO row: in a dense product
+            // 0 * Inf = NaN, so a fetched row with a non-finite element would poison the block
+            const int row = r.x < 0 ? -1 : (int)(((size_t)b * Lq + (r.x >> plan.lp_bits)) * H + h);
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
                 int rj = __shfl(row, j, 64);
+                const bool live = rj >= 0;
+                rj = live ? rj : 0;
                 if (BOXATTN_TUNE_MFMA_ABLATE & 32) rj = (rj & 63) + (int)((size_t)b * Lq * H);   // 64 hot rows
-                grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
+                grow[ps] = live ? t : u32x4{0u, 0u, 0u, 0u};
             }
         };
         // G^T[c][j] = row j, channel c.  Transposing 16-bit elements one ds_write_b16 at a time
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;     // wave-uniform
-            int4 rec_n3 = make_int4(0, 0, 0, 0);
+            int4 rec_n3 = make_int4(-1, 0, 0, 0);
             if (rr + 2 * R < item.z) {
                 fetch_rows(rec_n2, grow2);
                 rec_n3 = fetch_rec(rr + 3 * R);

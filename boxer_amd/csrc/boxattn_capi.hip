@@ -152,7 +152,8 @@ inline int finish()
 
 // ---- optional kernel timing (boxattn_profile_begin/_end) -------------------------------
 struct EventPair { hipEvent_t a, b; };
-enum { kSlotFwd = 0, kSlotBwdPoints = 1, kSlotBwdAccum = 2, kSlotBwdBin = 3, kNumSlots = 4 };
+enum { kSlotFwd = 0, kSlotBwdPoints = 1, kSlotBwdAccum = 2, kSlotBwdBin = 3, kSlotBwdCombine = 4,
+       kSlotBwdPrep = 5, kNumSlots = BOXATTN_PROFILE_SLOTS };
 struct Profile {
     bool on = false;
     std::vector<EventPair> ev[kNumSlots];
@@ -503,6 +504,9 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
         p.lv[l].blk0 = (int)blk0;
         blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
     }
+    // ... and the levels cover all of S: the binned kernels only store the rows a level block
+    // owns, a padded tail (S > sum H_l W_l) would stay uninitialised (the atomic path zero-fills)
+    if (next_start != d.S) return false;
     const long long rec_cap = 4ll * d.Lq * d.L * d.P;
     if (blk0 == 0 || blk0 > kMaxBlocks || rec_cap > INT32_MAX / 2 ||
         (long long)d.B * d.Lq * d.H > INT32_MAX || (long long)d.B * d.Lq * d.P * d.H > INT32_MAX)
@@ -700,8 +704,11 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                                dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
                                d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
     }
-    hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
-                       n_items, partials, plan, d.S, d.H, grad_value);
+    {
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
+        hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
+                           n_items, partials, plan, d.S, d.H, grad_value);
+    }
     side.join();
     return finish();
 }
@@ -730,7 +737,9 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
-        if (g_variant == 3 || plan_ready) return (int)hipErrorInvalidValue;
+        // (a plan the forward built is simply not used when the backward's own checks -- e.g. an
+        // unaligned grad_out view -- rule the binned path out: the atomic path needs no plan)
+        if (g_variant == 3) return (int)hipErrorInvalidValue;
         float *acc = nullptr;
         if constexpr (kBf16) {
             if (!workspace || workspace_bytes < nv * sizeof(float)) return (int)hipErrorInvalidValue;
@@ -774,7 +783,10 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
     BinPlan plan;
     bool ok = (g_variant == 0 || g_variant >= 3) && workspace && d.valid() &&
               d.n_value() && d.n_qh() && make_plan(d, shapes_host, lsi_host, plan) &&
-              aligned(workspace, 256) && aligned(loc, 8);
+              aligned(workspace, 256) &&
+              // what the backward will check and the forward can already see (its other operands,
+              // grad_out / grad_value, are re-checked there; an ineligible backward ignores the plan)
+              fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out, out);
     WsLayout w{};
     if (ok) {
         w = ws_layout(d, plan, wide_workspace(std::is_same<ST, bf16_t>::value));
@@ -907,7 +919,7 @@ const char *boxattn_build_info(void)
 {
     return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
            " | kernels: generic{f32,f64,bf16}, gather{f32 4ch/lane, bf16 8ch/lane} C={16,32,64}, "
-           "binned-bwd{f32,bf16}, box-grid{f32} | abi 5";
+           "binned-bwd{f32,bf16}, box-grid{f32} | abi 6";
 }
 
 int boxattn_profile_begin(void)

@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 5
+#define BOXATTN_ABI_VERSION 6
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -239,17 +239,19 @@ int boxattn_set_variant(int variant);
 /*
  * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the
  * library brackets the launches of its main kernels with hipEvents recorded on the launch
- * stream, in four slots:
+ * stream, in BOXATTN_PROFILE_SLOTS slots:
  *   0  forward sampling kernel
  *   1  backward, point gradients (grad_loc / grad_weight) -- or the whole atomic backward
  *      kernel when the binned algorithm is not used
- *   2  backward, grad_value accumulate kernel of the binned algorithm
- *   3  backward, binning passes (count + scan + fill)
+ *   2  backward, grad_value accumulate kernel
+ *   3  backward, binning passes (count + scan + fill) of the binned algorithm
+ *   4  backward, combine pass over the partial tiles of split blocks
+ *   5  backward, preparation pass of the query-grid algorithm (tile bounding boxes)
  * Zero-fills and the bf16 conversion pass are not included.  _end synchronises the events and
  * writes, per slot, the summed duration in milliseconds and the number of launches into the two
- * 4-element arrays.  At most 4096 launches per slot are kept.
+ * BOXATTN_PROFILE_SLOTS-element arrays.  At most 4096 launches per slot are kept.
  */
-#define BOXATTN_PROFILE_SLOTS 4
+#define BOXATTN_PROFILE_SLOTS 6
 int boxattn_profile_begin(void);
 int boxattn_profile_end(double *ms_sum, int *launches);
 

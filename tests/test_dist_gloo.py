@@ -59,3 +59,32 @@ def test_bench_protocol_world2(tmp_path):
     assert abs(r["ms"] - r["elapsed"] / 5 * 1e3) < 1e-9
     sigs = r["sigs"]
     assert sigs[0, 1] == sigs[1, 1] and sigs[0, 0] != sigs[1, 0]   # same shape, own data
+
+
+_CHILD = """
+import os, sys, torch, torch.distributed as dist
+dist.init_process_group("gloo")          # RANK / WORLD_SIZE / MASTER_* from bench.spawn_ranks
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+if dist.get_rank() == 0:
+    print("SUM=%d WORLD=%d LOCAL=%s" % (int(t.item()), dist.get_world_size(), os.environ["LOCAL_RANK"]))
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if int(t.item()) == 3 else 5)
+"""
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launcher_starts_its_ranks(tmp_path, capfd):
+    """``python bench.py --gpus N`` without a launcher: bench.spawn_ranks starts N fresh children
+    with the rendezvous environment; here the children run a gloo all-reduce instead of the GPU
+    bench (the reference's launcher: tools/run.py:59-75)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    env_before = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "MASTER_PORT")}
+    rc = bench.spawn_ranks(2, cmd=[sys.executable, str(script)])
+    assert rc == 0
+    assert "SUM=3 WORLD=2 LOCAL=0" in capfd.readouterr().out
+    assert env_before == {k: os.environ.get(k) for k in env_before}      # parent env untouched
