@@ -37,13 +37,18 @@ _WS_SIGNATURES = {
     "instattn_fwd_train": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
                                                           _vp],
 }
+_HL_SIGNATURES = {
+    # forward args + shapes_host, lsi_host, stream
+    "boxattn_fwd_hl": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp],
+}
 _GRID_SIGNATURES = {
     # ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios, [grad_grid,]
     # B, Lq, H, L, P, outputs..., stream
     "boxattn_grid_fwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp] + [_i] * 5 + [_vp, _vp],
     "boxattn_grid_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp],
 }
-EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant",
+EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "boxattn_set_option",
+           "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
@@ -111,6 +116,13 @@ def load():
             fn = getattr(lib, "%s_%s" % (stem, suf))
             fn.argtypes = args
             fn.restype = _i
+    for stem, args in _HL_SIGNATURES.items():
+        for suf in ("f32", "bf16"):
+            fn = getattr(lib, "%s_%s" % (stem, suf))
+            fn.argtypes = args
+            fn.restype = _i
+    lib.boxattn_set_option.argtypes = [_i, _i]
+    lib.boxattn_set_option.restype = _i
     for name, args in _GRID_SIGNATURES.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = _i
@@ -130,6 +142,15 @@ def set_variant(v):
     """0 = auto, 1 = generic kernels only, 2 = fast atomic kernels only, 3 = binned backward
     only (2 and 3 return an error when the shape is not eligible)."""
     return load().boxattn_set_variant(int(v))
+
+
+OPTIONS = {"tile_shape": 0, "tile_rows": 1, "tile_margin_cap": 2, "tile_static_q16": 3,
+           "tile_ablate": 4, "qg_target": 5, "tile_fwd": 6, "qg_ablate": 7, "qg_waves": 8, "qg_bwd": 9}
+
+
+def set_option(name, value):
+    """Tuning knobs for A/B runs (include/boxattn.h: boxattn_set_option); returns the old value."""
+    return load().boxattn_set_option(OPTIONS[name], int(value))
 
 
 def profile_begin():

@@ -128,25 +128,23 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
         auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {
             if (BOXATTN_TUNE_MFMA_ABLATE & 2) return;
-            // idle lanes (past the item's last record) contribute a ZERO row: in a dense product
-            // 0 * Inf = NaN, so a fetched row with a non-finite element would poison the block
-            const int row = r.x < 0 ? -1 : (int)(((size_t)b * Lq + (r.x >> plan.lp_bits)) * H + h);
+            // (idle lanes, id -1, fetch row 0; it is zeroed when staged)
+            const int row = (int)(((size_t)b * Lq + (max(r.x, 0) >> plan.lp_bits)) * H + h);
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
                 int rj = __shfl(row, j, 64);
-                const bool live = rj >= 0;
-                rj = live ? rj : 0;
                 if (BOXATTN_TUNE_MFMA_ABLATE & 32) rj = (rj & 63) + (int)((size_t)b * Lq * H);   // 64 hot rows
-                const u32x4 t = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
-                grow[ps] = live ? t : u32x4{0u, 0u, 0u, 0u};
+                grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
             }
         };
         // G^T[c][j] = row j, channel c.  Transposing 16-bit elements one ds_write_b16 at a time
         // was 17 of this kernel's 51 us; instead the lanes of records j and j + 1 (same 16-byte
         // piece) swap halves with DPP, and each writes whole dwords {G[j][c], G[j+1][c]}: the even
         // record's lane for the piece's even channels, the odd one's for the odd channels.
-        auto stage_rows = [&]() {
+        // n_live: records of the round being staged; the rows of idle lanes are staged as ZEROS (in a
+        // dense product 0 * Inf = NaN: a fetched row with a non-finite element would poison the block)
+        auto stage_rows = [&](int n_live) {
             if (BOXATTN_TUNE_MFMA_ABLATE & 3) return;
             if (BOXATTN_TUNE_MFMA_ABLATE & 16) {    // rows gathered and waited for, not staged
                 unsigned x = 0;
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                     reinterpret_cast<unsigned int *>(&gt[(piece * 8 + odd) * GS + (j & ~1)]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned own = grow[ps][i];
+                    const unsigned own = j < n_live ? grow[ps][i] : 0u;
                     const unsigned oth = pair_exchange<LPR>(own);       // lane ^ LPR: record j ^ 1
                     dst[i * GS] = __builtin_amdgcn_perm(oth, own, sel);   // rows 2 i + odd, GS ushorts apart
                 }
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         // of its time waiting for them), records three
         int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
         fetch_rows(rec_c, grow);
-        stage_rows();
+        stage_rows(min(R, item.z - item.y));
         if (item.y + R < item.z) fetch_rows(rec_n, grow);
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
@@ -252,7 +250,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             for (int k = 0; k < 4; ++k)
                 if (slot[k] >= 0 && !(BOXATTN_TUNE_MFMA_ABLATE & 8)) at[slot[k]] = 0;
             if (more) {
-                stage_rows();
+                stage_rows(min(R, item.z - rr - R));
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) grow[ps] = grow2[ps];
                 rec_c = rec_n; rec_n = rec_n2; rec_n2 = rec_n3;

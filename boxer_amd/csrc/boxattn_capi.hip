@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -19,6 +20,8 @@
 #include "boxattn_gather2.h"
 #include "boxattn_generic.h"
 #include "boxattn_grid.h"
+#include "boxattn_qgrid.h"
+#include "boxattn_tile.h"
 
 using namespace boxattn;
 
@@ -26,7 +29,14 @@ namespace {
 
 // 0 auto | 1 generic kernels only | 2 fast atomic kernels (error if the shape does not qualify,
 // never the binned backward) | 3 binned backward required (error if not eligible)
-int g_variant = 0;
+// 7 = like 0 without the query-grid (LDS-tiled) kernels
+std::atomic<int> g_variant{0};
+
+// Tuning options (boxattn_set_option): process-wide knobs for A/B runs, relaxed atomics.
+enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStatic = 3, kOptTileAblate = 4,
+       kOptQgTarget = 5, kOptTileFwd = 6, kOptQgAblate = 7, kOptQgWaves = 8, kOptQgBwd = 9, kNumOpts = 12 };
+std::atomic<int> g_opt[kNumOpts];      // 0 = default
+inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
 inline int ceil_div_sz(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 
@@ -155,7 +165,8 @@ struct EventPair { hipEvent_t a, b; };
 enum { kSlotFwd = 0, kSlotBwdPoints = 1, kSlotBwdAccum = 2, kSlotBwdBin = 3, kSlotBwdCombine = 4,
        kSlotBwdPrep = 5, kNumSlots = BOXATTN_PROFILE_SLOTS };
 struct Profile {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;                          // forward and backward run on different host threads
     std::vector<EventPair> ev[kNumSlots];
 } g_prof;
 constexpr size_t kMaxProfiled = 4096;
@@ -166,7 +177,7 @@ struct ScopedKernelTimer {            // brackets one kernel launch when profili
     std::vector<EventPair> *dst = nullptr;
     ScopedKernelTimer(std::vector<EventPair> &v, hipStream_t s) : st(s)
     {
-        if (!g_prof.on || v.size() >= kMaxProfiled) return;
+        if (!g_prof.on.load(std::memory_order_relaxed)) return;
         if (hipEventCreate(&ev.a) != hipSuccess) return;
         if (hipEventCreate(&ev.b) != hipSuccess) { (void)hipEventDestroy(ev.a); return; }
         dst = &v;
@@ -176,7 +187,9 @@ struct ScopedKernelTimer {            // brackets one kernel launch when profili
     {
         if (!dst) return;
         (void)hipEventRecord(ev.b, st);
-        dst->push_back(ev);
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        if (dst->size() < kMaxProfiled) dst->push_back(ev);
+        else { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     }
 };
 
@@ -199,13 +212,98 @@ inline void drain(std::vector<EventPair> &v, double *ms_sum, int *n)
     if (n) *n = cnt;
 }
 
+// ------------------------------------------------------ query-grid kernels (boxattn_tile.h)
+struct TileShape { int tx, ty; };
+template <typename ST> inline TileShape tile_shape()
+{
+    // option kOptTileShape: 1 = 16 x 8 queries (512 threads), 2 = 8 x 8 (256 threads)
+    const int o = opt(kOptTileShape);
+    if (o == 1) return {16, 8};
+    if (o == 2) return {8, 8};
+    return sizeof(ST) == 2 ? TileShape{16, 8} : TileShape{8, 8};
+}
+// LDS rows for the windows of one workgroup: two workgroups per CU (160 KiB) by default
+template <typename ST> inline int tile_row_budget(const Dims &d)
+{
+    const int rowb = d.C * (int)sizeof(ST);
+    const int o = opt(kOptTileRows);
+    const int rows = o > 0 ? o : (78 * 1024) / rowb;
+    return std::min(rows, (158 * 1024) / rowb);
+}
+// The encoder case: one query per pixel of the packed multi-level map, BoxeR's head geometry.
+template <typename ST>
+inline bool make_tile_plan(const Dims &d, const int64_t *sh, const int64_t *ls, TileShape ts,
+                           TilePlan &p)
+{
+    if (!sh || !ls || g_variant == 1 || g_variant == 2 || g_variant == 7) return false;
+    // (measured slower than the row gathers so far -- both are instruction-bound, DESIGN.md 4.1 --
+    // so the kernel is opt-in: option kOptTileFwd = 1)
+    if (opt(kOptTileFwd) != 1) return false;
+    if (d.Lq != d.S || d.C != 32 || d.L > kTileMaxLevels || d.P % 4 != 0) return false;
+    const int nr = d.L * d.P / 4;
+    if (nr != 2 && nr != 4) return false;
+    if ((size_t)d.B * d.S * d.H * d.C * sizeof(ST) >= kOobOffset ||
+        (size_t)d.B * d.Lq * d.H >= (1ull << 31) / 64)
+        return false;
+    long long next = 0, tiles = 0;
+    p.L = d.L;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1];
+        if (hl <= 0 || wl <= 0 || hl > 32000 || wl > 32000 || ls[l] != next) return false;
+        next += hl * wl;
+        const long long ntx = (wl + ts.tx - 1) / ts.tx, nty = (hl + ts.ty - 1) / ts.ty;
+        p.lv[l] = TileLevel{(int)hl, (int)wl, (int)ls[l], (int)ntx, (int)tiles, 1.0f / (float)wl,
+                            1.0f / (float)hl};
+        tiles += ntx * nty;
+    }
+    if (next != d.S || tiles * d.B * d.H >= (1ll << 31)) return false;
+    p.n_tiles = (int)tiles;
+    p.row_budget = tile_row_budget<ST>(d);
+    p.margin_cap = opt(kOptTileMarginCap) > 0 ? opt(kOptTileMarginCap) : 24;
+    p.static_q16 = opt(kOptTileStatic);
+    p.ablate = opt(kOptTileAblate);
+    return true;
+}
+
+template <typename K> inline hipError_t allow_dynamic_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename ST>
+int launch_fwd_tile(const ST *value, const float *loc, const float *attn, const Dims &d,
+                    const TilePlan &plan, TileShape ts, ST *out, hipStream_t st)
+{
+    const size_t lds = (size_t)plan.row_budget * d.C * sizeof(ST);
+    const unsigned grid = (unsigned)((size_t)d.B * plan.n_tiles * d.H);
+    const unsigned vbytes = (unsigned)(d.n_value() * sizeof(ST));
+    const int nr = d.L * d.P / 4;
+#define BOXATTN_FWD_TILE(NR_, TX_, TY_)                                                         \
+    do {                                                                                        \
+        auto k = fwd_tile_kernel<ST, NR_, TX_, TY_>;                                            \
+        hipError_t e = allow_dynamic_lds(k, lds);                                               \
+        if (e != hipSuccess) return (int)e;                                                     \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(TX_ * TY_ * 4), lds, st, value, loc, attn, plan, \
+                           d.S, d.H, d.Lq, d.P, out, vbytes);                                   \
+    } while (0)
+    if (ts.tx == 16) {
+        if (nr == 4) BOXATTN_FWD_TILE(4, 16, 8); else BOXATTN_FWD_TILE(2, 16, 8);
+    } else {
+        if (nr == 4) BOXATTN_FWD_TILE(4, 8, 8); else BOXATTN_FWD_TILE(2, 8, 8);
+    }
+#undef BOXATTN_FWD_TILE
+    return finish();
+}
+
 // ------------------------------------------------------------------------------ forward
 template <typename ST, bool INST>
 int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                const typename Storage<ST>::compute *loc,
                const typename Storage<ST>::compute *w_sp,
                const typename Storage<ST>::compute *w_lv, const Dims &d, ST *out, ST *mask,
-               hipStream_t st)
+               hipStream_t st, const int64_t *shapes_host = nullptr,
+               const int64_t *lsi_host = nullptr)
 {
     if (!d.valid()) return (int)hipErrorInvalidValue;
     if (d.empty()) return 0;                                   // no queries: nothing to write
@@ -222,6 +320,15 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     if constexpr (!std::is_same<ST, double>::value) {
         if (fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out,
                         out)) {
+            if constexpr (!INST) {          // encoder case: LDS-staged value windows
+                TilePlan tp;
+                const TileShape ts = tile_shape<ST>();
+                if (aligned(value, 16) && aligned(out, 16) &&
+                    make_tile_plan<ST>(d, shapes_host, lsi_host, ts, tp)) {
+                    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+                    return launch_fwd_tile<ST>(value, loc, w_sp, d, tp, ts, out, st);
+                }
+            }
             const size_t vbytes = d.n_value() * sizeof(ST);
             GatherIdx ix{};
             const bool gen2 = g_variant != 2 && vbytes < kOobOffset && gather_idx(d, ix, sizeof(ST));   // buffer-load kernels
@@ -607,6 +714,59 @@ inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, c
 #undef BOXATTN_BIN
 }
 
+// Point gradients (grad_loc / grad_weight): query-major gathers, independent of how grad_value
+// is accumulated.
+template <typename ST, int G, bool INST>
+void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                      const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
+                      const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
+{
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
+    const size_t n_qh = d.n_qh();
+    const size_t vbytes = d.n_value() * sizeof(ST);
+    GatherIdx ix{};
+    if (vbytes < kOobOffset && gather_idx(d, ix, sizeof(ST))) {
+        const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
+                                                (!INST || aligned(grad_mask, 16)));
+        const int blocks = gather_blocks(d, ix, kWave / cfg.G);
+        // few pairs x many points (instance attention on the mask-decoder grid): one wave
+        // per pair, its lane groups over the point tiles; else one lane group per pair
+#ifndef BOXATTN_TUNE_PG_WAVE_PER_PAIR
+#define BOXATTN_TUNE_PG_WAVE_PER_PAIR 1
+#endif
+        const int tiles = (d.L * d.P + cfg.G - 1) / cfg.G;
+        const bool wpp = BOXATTN_TUNE_PG_WAVE_PER_PAIR && INST && g_variant != 5 &&
+                         blocks < 1024 && tiles >= kWave / cfg.G;
+        if (wpp) {
+            const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
+                                            : ceil_div_sz(n_qh, 4);
+            const int split = point_split(wblocks, tiles / (kWave / cfg.G));
+#define BOXATTN_PG2W(GG, VV)                                                                         \
+hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
+                   dim3(wblocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
+                   grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
+                   ix, (unsigned)vbytes);
+            BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
+#undef BOXATTN_PG2W
+        } else {
+            const int split = point_split(blocks, tiles);
+#define BOXATTN_PG2(GG, VV)                                                                   \
+hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
+                   dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
+                   w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
+                   grad_lv, ix, (unsigned)vbytes);
+            BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
+#undef BOXATTN_PG2
+        }
+    } else {
+        const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
+        hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
+                           0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
+                           d.S, d.H, d.L, d.Lq, d.P, (float *)nullptr, grad_loc, grad_sp, grad_lv,
+                           n_qh);
+    }
+}
+
 template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
@@ -624,53 +784,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // in-order stream (also valid under stream capture).
     SideStream side(st, side_stream_worth<ST>(d));
     if (!plan_ready) launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, ws, st);
-    {
-        hipStream_t st = side.stream();                       // shadows: launch on the side stream
-        ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
-        const size_t n_qh = d.n_qh();
-        const size_t vbytes = d.n_value() * sizeof(ST);
-        GatherIdx ix{};
-        if (vbytes < kOobOffset && gather_idx(d, ix, sizeof(ST))) {
-            const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16) &&
-                                                    (!INST || aligned(grad_mask, 16)));
-            const int blocks = gather_blocks(d, ix, kWave / cfg.G);
-            // few pairs x many points (instance attention on the mask-decoder grid): one wave
-            // per pair, its lane groups over the point tiles; else one lane group per pair
-#ifndef BOXATTN_TUNE_PG_WAVE_PER_PAIR
-#define BOXATTN_TUNE_PG_WAVE_PER_PAIR 1
-#endif
-            const int tiles = (d.L * d.P + cfg.G - 1) / cfg.G;
-            const bool wpp = BOXATTN_TUNE_PG_WAVE_PER_PAIR && INST && g_variant != 5 &&
-                             blocks < 1024 && tiles >= kWave / cfg.G;
-            if (wpp) {
-                const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
-                                                : ceil_div_sz(n_qh, 4);
-                const int split = point_split(wblocks, tiles / (kWave / cfg.G));
-#define BOXATTN_PG2W(GG, VV)                                                                         \
-    hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
-                       dim3(wblocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
-                       grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
-                       ix, (unsigned)vbytes);
-                BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
-#undef BOXATTN_PG2W
-            } else {
-                const int split = point_split(blocks, tiles);
-#define BOXATTN_PG2(GG, VV)                                                                   \
-    hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
-                       dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
-                       w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
-                       grad_lv, ix, (unsigned)vbytes);
-                BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
-#undef BOXATTN_PG2
-            }
-        } else {
-            const int blocks = ceil_div_sz(n_qh, (size_t)(kWave / G) * 4);
-            hipLaunchKernelGGL((bwd_fast_kernel<ST, 4, G, INST, false>), dim3(blocks), dim3(256),
-                               0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
-                               d.S, d.H, d.L, d.Lq, d.P, (float *)nullptr, grad_loc, grad_sp, grad_lv,
-                               n_qh);
-        }
-    }
+    launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
+                                  grad_sp, grad_lv, side.stream());
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
     // real count lives on the device, surplus workgroups exit at once); the hardware dispatcher
     // hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
@@ -713,6 +828,121 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     return finish();
 }
 
+// ------------------------------------------------- query-grid backward (boxattn_qgrid.h)
+struct QgLayout { size_t bbox, cand, cand_w, partials, total; };
+
+// Encoder case (Lq == S, packed levels), BoxeR's head geometry, bf16 storage, 2x2 grids.
+inline bool make_qg_plan(const Dims &d, const int64_t *sh, const int64_t *ls, QgPlan &p)
+{
+    if (!sh || !ls || !d.valid() || g_variant == 1 || g_variant == 2 || g_variant == 3 || g_variant == 8)
+        return false;
+    // (measured slower than the binned backward so far -- 21 + 118 + 10 us against 50 + 57 + 8 at
+    // BoxeR-R50 shapes, DESIGN.md 4.2 -- so the path is opt-in: option kOptQgBwd = 1)
+    if (opt(kOptQgBwd) != 1) return false;
+    if (d.Lq != d.S || d.C != 32 || d.P != 4 || d.L > kQgMaxLevels) return false;
+    if ((size_t)d.B * d.Lq * d.H * d.C >= (1ull << 31)) return false;       // 32-bit row ids
+    long long next = 0, tiles = 0, items = 0, parts = 0;
+    const int target = opt(kOptQgTarget) > 0 ? opt(kOptQgTarget) : 512;     // records per item
+    p.L = d.L;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1];
+        if (hl <= 0 || wl <= 0 || hl > 32000 || wl > 32000 || ls[l] != next) return false;
+        next += hl * wl;
+        QgLevel &v = p.lv[l];
+        v.H = (int)hl; v.W = (int)wl; v.start = (int)ls[l];
+        v.ntx4 = (int)((wl + 3) / 4);
+        v.tile0 = (int)tiles;
+        tiles += (long long)v.ntx4 * ((hl + 3) / 4);
+        const long long nbx = (wl + 7) / 8, nby = (hl + 3) / 4;
+        // expected records per block: every query puts P points on every level, a record per
+        // block its footprint meets (~1.3)
+        const double per_block = (double)d.Lq * d.P * 1.3 / (double)(nbx * nby);
+        v.gx = v.gy = 1;
+        v.cpb = 1;
+        if (per_block * 4 <= target * 1.5) v.gx = v.gy = 2;
+        else if (per_block * 2 <= target * 1.25) v.gx = 2;
+        else v.cpb = (int)std::max(1.0, std::min(4096.0, per_block / target + 0.5));
+        v.ngx = (int)((nbx + v.gx - 1) / v.gx);
+        v.ngy = (int)((nby + v.gy - 1) / v.gy);
+        v.item0 = (int)items;
+        items += (long long)v.ngx * v.ngy * v.cpb;
+        v.part0 = v.cpb > 1 ? (int)parts : -1;
+        if (v.cpb > 1) parts += (long long)v.ngx * v.ngy * v.cpb;
+    }
+    if (next != d.S || tiles > 65535 || items > (1 << 20) || parts > (1 << 20)) return false;
+    for (int l = 0; l < d.L; ++l)
+        p.lv[l].cpb = std::min<long long>(p.lv[l].cpb, tiles);
+    p.n_tiles4 = (int)tiles;
+    p.n_items = (int)items;
+    p.n_parts = (int)parts;
+    p.ablate = opt(kOptQgAblate);
+    return true;
+}
+
+inline QgLayout qg_layout(const Dims &d, const QgPlan &p)
+{
+    QgLayout w;
+    const size_t ns = (size_t)d.B * d.H;
+    size_t o = 0;
+    w.bbox = o;     o += align_up(ns * d.L * (size_t)p.n_tiles4 * sizeof(uint2));
+    w.cand = o;     o += align_up(ns * d.L * (size_t)p.n_tiles4 * 64 * sizeof(int4));
+    w.cand_w = o;   o += align_up(ns * d.L * (size_t)p.n_tiles4 * 64 * sizeof(float));
+    w.partials = o; o += align_up(ns * (size_t)p.n_parts * 32 * d.C * sizeof(float));
+    w.total = o;
+    return w;
+}
+
+inline int launch_qg_prep(const float *loc, const float *attn, const Dims &d, const QgPlan &p,
+                          const QgLayout &w, char *ws, hipStream_t st)
+{
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdPrep], st);
+    const unsigned waves = (unsigned)((size_t)d.B * d.H * p.n_tiles4);
+    uint2 *bbox = (uint2 *)(ws + w.bbox);
+    int4 *cand = (int4 *)(ws + w.cand);
+    float *cand_w = (float *)(ws + w.cand_w);
+#define BOXATTN_QG_BBOX(LV_)                                                                     \
+    case LV_:                                                                                    \
+        hipLaunchKernelGGL((qg_prep_kernel<LV_>), dim3((waves + 3) / 4), dim3(256), 0, st, loc,  \
+                           attn, p, d.B, d.H, d.Lq, bbox, cand, cand_w);                         \
+        break;
+    switch (d.L) {
+        BOXATTN_QG_BBOX(1) BOXATTN_QG_BBOX(2) BOXATTN_QG_BBOX(3) BOXATTN_QG_BBOX(4)
+        BOXATTN_QG_BBOX(5) BOXATTN_QG_BBOX(6) BOXATTN_QG_BBOX(7) BOXATTN_QG_BBOX(8)
+    }
+#undef BOXATTN_QG_BBOX
+    return finish();
+}
+
+// grad_value of bf16 box attention on a query grid: [tile boxes] -> accumulate -> combine
+inline int run_qgrid(const bf16_t *grad_out, const float *loc, const float *attn, const Dims &d,
+                     const QgPlan &p, const QgLayout &w, char *ws, bf16_t *grad_value,
+                     bool boxes_ready, hipStream_t st)
+{
+    int rc = 0;
+    if (!boxes_ready && (rc = launch_qg_prep(loc, attn, d, p, w, ws, st))) return rc;
+    const int ns = d.B * d.H;
+    uint2 *bbox = (uint2 *)(ws + w.bbox);
+    float *partials = (float *)(ws + w.partials);
+    {
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
+        // persistent waves: 12 per CU (registers / LDS of the kernel), 32 CUs per XCD
+        const int per_xcd_items = ((ns + 7) / 8) * p.n_items;
+        const int waves = std::max(1, std::min(opt(kOptQgWaves) > 0 ? opt(kOptQgWaves) : 12 * 32, per_xcd_items));
+        hipLaunchKernelGGL((qg_accumulate_kernel<32>), dim3(8 * waves), dim3(64), 0, st, grad_out,
+                           bbox, (const int4 *)(ws + w.cand), (const float *)(ws + w.cand_w), p, ns,
+                           d.S, d.H, grad_value, partials);
+    }
+    int split_groups = 0;
+    for (int l = 0; l < p.L; ++l)
+        if (p.lv[l].cpb > 1) split_groups += p.lv[l].ngx * p.lv[l].ngy;
+    if (split_groups) {
+        ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
+        hipLaunchKernelGGL((qg_combine_kernel<32>), dim3(split_groups, ns), dim3(128), 0, st,
+                           partials, p, d.S, d.H, grad_value);
+    }
+    return finish();
+}
+
 // Backward with a caller-provided workspace; falls back to the atomic kernels when the
 // binned algorithm does not apply.
 template <typename ST, bool INST>
@@ -720,8 +950,10 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                  size_t workspace_bytes, bool plan_ready, hipStream_t st)
+                  size_t workspace_bytes, int plan_kind, hipStream_t st)
 {
+    // plan_kind: what the training forward left in the workspace -- 0 nothing, 1 the binning
+    // plan, 2 the query-grid tile boxes (the value *_fwd_train_* returned in *plan_built)
     constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
     if (!d.valid()) return (int)hipErrorInvalidValue;
     BinPlan plan;
@@ -731,6 +963,24 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   fast_ok<ST>(d, value, loc, grad_out,
                               INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
                   aligned(workspace, 256) && aligned(grad_value, 16);
+    if constexpr (kBf16 && !INST) {      // encoder case: no global binning (boxattn_qgrid.h)
+        QgPlan qp;
+        if (binned && plan_kind != 1 && aligned(grad_out, 16) && aligned(loc, 16) &&
+            make_qg_plan(d, shapes_host, lsi_host, qp)) {
+            const QgLayout qw = qg_layout(d, qp);
+            if (workspace_bytes >= qw.total) {
+                if (!shapes || !lsi || !loc || !w_sp || !grad_out || !grad_loc || !grad_sp ||
+                    !grad_value || !value)
+                    return (int)hipErrorInvalidValue;
+                launch_pointgrad<ST, 8, false>(value, shapes, lsi, loc, w_sp, w_lv, grad_out,
+                                               grad_mask, d, grad_loc, grad_sp, grad_lv, st);
+                return run_qgrid(grad_out, loc, w_sp, d, qp, qw, (char *)workspace, grad_value,
+                                 plan_kind == 2, st);
+            }
+        }
+        if (plan_kind == 2) plan_kind = 0;     // boxes in the workspace, but the binned path runs
+    }
+    const bool plan_ready = plan_kind == 1;
     WsLayout w{};
     if (binned) {
         w = ws_layout(d, plan, wide_workspace(kBf16));
@@ -792,10 +1042,26 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         w = ws_layout(d, plan, wide_workspace(std::is_same<ST, bf16_t>::value));
         ok = workspace_bytes >= w.total;
     }
-    if (!ok) return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
+    if (!ok)
+        return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                    shapes_host, lsi_host);
+    if constexpr (std::is_same<ST, bf16_t>::value && !INST) {      // query grid: tile boxes only
+        QgPlan qp;
+        if (aligned(loc, 16) && make_qg_plan(d, shapes_host, lsi_host, qp)) {
+            const QgLayout qw = qg_layout(d, qp);
+            if (workspace_bytes >= qw.total) {
+                int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                              shapes_host, lsi_host);
+                if (rc == 0) rc = launch_qg_prep(loc, w_sp, d, qp, qw, (char *)workspace, st);
+                if (rc == 0 && plan_built) *plan_built = 2;
+                return rc;
+            }
+        }
+    }
     SideStream side(st, side_stream_worth<ST>(d));
     launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, (char *)workspace, side.stream());
-    const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st);
+    const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                        shapes_host, lsi_host);
     side.join();
     if (rc == 0 && plan_built) *plan_built = 1;
     return rc;
@@ -859,7 +1125,11 @@ size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int 
     const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
     BinPlan plan;
     if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
-    return std::max(fallback, ws_layout(d, plan, wide_workspace(is_bf16 != 0)).total);
+    size_t need = std::max(fallback, ws_layout(d, plan, wide_workspace(is_bf16 != 0)).total);
+    QgPlan qp;
+    if (is_bf16 && make_qg_plan(d, shapes_host, lsi_host, qp))
+        need = std::max(need, qg_layout(d, qp).total);
+    return need;
 }
 
 int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -871,7 +1141,7 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
     return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
                                        Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                       workspace_bytes, plan_ready != 0, (hipStream_t)stream);
+                                       workspace_bytes, plan_ready, (hipStream_t)stream);
 }
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
@@ -883,7 +1153,7 @@ int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int6
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr,
                                         Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                         grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                        workspace_bytes, plan_ready != 0, (hipStream_t)stream);
+                                        workspace_bytes, plan_ready, (hipStream_t)stream);
 }
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
@@ -896,7 +1166,7 @@ int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t
     return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
                                       grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                       grad_spatial_w, grad_level_w, shapes_host, lsi_host,
-                                      workspace, workspace_bytes, plan_ready != 0, (hipStream_t)stream);
+                                      workspace, workspace_bytes, plan_ready, (hipStream_t)stream);
 }
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
@@ -909,7 +1179,7 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
     return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out,
                                        grad_mask, Dims{B, S, H, C, L, Lq, P}, grad_value, grad_loc,
                                        grad_spatial_w, grad_level_w, shapes_host, lsi_host,
-                                       workspace, workspace_bytes, plan_ready != 0, (hipStream_t)stream);
+                                       workspace, workspace_bytes, plan_ready, (hipStream_t)stream);
 }
 
 
@@ -924,6 +1194,7 @@ const char *boxattn_build_info(void)
 
 int boxattn_profile_begin(void)
 {
+    std::lock_guard<std::mutex> g(g_prof.mu);
     for (auto &v : g_prof.ev) drain(v, nullptr, nullptr);
     g_prof.on = true;
     return 0;
@@ -932,16 +1203,18 @@ int boxattn_profile_begin(void)
 int boxattn_profile_end(double *ms_sum, int *launches)
 {
     g_prof.on = false;
+    std::lock_guard<std::mutex> g(g_prof.mu);
     for (int i = 0; i < kNumSlots; ++i)
         drain(g_prof.ev[i], ms_sum ? ms_sum + i : nullptr, launches ? launches + i : nullptr);
     return 0;
 }
 
-int boxattn_set_variant(int variant)
+int boxattn_set_variant(int variant) { return g_variant.exchange(variant); }
+
+int boxattn_set_option(int key, int value)
 {
-    const int old = g_variant;
-    g_variant = variant;
-    return old;
+    if (key < 0 || key >= kNumOpts) return -1;
+    return g_opt[key].exchange(value);
 }
 
 #define DIMS Dims{B, S, H, C, L, Lq, P}
@@ -967,6 +1240,23 @@ int boxattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t
 {
     return launch_fwd<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out,
                                      nullptr, ST_);
+}
+
+int boxattn_fwd_hl_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                       int Lq, int P, float *out, const int64_t *shapes_host,
+                       const int64_t *lsi_host, void *stream)
+{
+    return launch_fwd<float, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out, nullptr,
+                                    ST_, shapes_host, lsi_host);
+}
+int boxattn_fwd_hl_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                        int Lq, int P, uint16_t *out, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *stream)
+{
+    return launch_fwd<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out, nullptr,
+                                     ST_, shapes_host, lsi_host);
 }
 
 int boxattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,

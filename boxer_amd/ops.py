@@ -93,10 +93,11 @@ class BackwardPlan:
     locations and -- bf16 box attention, whose records carry them -- the attention weights),
     plus what it is valid for."""
 
-    __slots__ = ("ws", "key")
+    __slots__ = ("ws", "key", "kind")
 
-    def __init__(self, ws, key):
-        self.ws, self.key = ws, key
+    def __init__(self, ws, key, kind=1):
+        # kind: 1 = binning plan, 2 = query-grid tile boxes (what *_fwd_train_* reported)
+        self.ws, self.key, self.kind = ws, key, kind
 
 
 def _plan_key(dims, loc, weights):
@@ -127,13 +128,13 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
                 ctypes.addressof(built), stream)
     if rc != 0:
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
-    return BackwardPlan(ws, _plan_key(dims, loc, weights)) if built.value else None
+    return BackwardPlan(ws, _plan_key(dims, loc, weights), built.value) if built.value else None
 
 
 def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
     """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
     lib = _lib.load()
-    ready = int(plan is not None and plan.key == _plan_key(dims, loc, weights))
+    ready = plan.kind if (plan is not None and plan.key == _plan_key(dims, loc, weights)) else 0
     if ready:
         ws, sh, ls = plan.ws, _host_table(shapes), _host_table(lsi)
     else:
@@ -164,7 +165,12 @@ def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, att
     B, S, H, C, L, Lq, P = dims
     _chunk_assert(B, im2col_step)
     out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
-    _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
+    if value.dtype == torch.float64:
+        _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
+    else:       # host copies of the level tables let the library recognise the encoder case
+        sh, ls = _host_table(spatial_shapes), _host_table(level_start_index)
+        _call("boxattn_fwd_hl", value, value, spatial_shapes, level_start_index, loc, attn, *dims,
+              out, sh.ctypes.data, ls.ctypes.data)
     return out
 
 

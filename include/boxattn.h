@@ -64,6 +64,19 @@ int boxattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t
                      const float *loc, const float *attn, int B, int S, int H, int C, int L,
                      int Lq, int P, uint16_t *out, void *stream);
 
+/* Forward with HOST copies of the two level tables next to the device ones (either may be
+ * NULL): lets the library recognise the encoder case -- one query per pixel of the packed
+ * multi-level map (Lq == S; box_transformer.py:346-354) -- and run the query-grid kernels
+ * (LDS-staged value windows) instead of the row gathers.  Same results as boxattn_fwd_*. */
+int boxattn_fwd_hl_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                       int Lq, int P, float *out, const int64_t *shapes_host,
+                       const int64_t *lsi_host, void *stream);
+int boxattn_fwd_hl_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *loc, const float *attn, int B, int S, int H, int C, int L,
+                        int Lq, int P, uint16_t *out, const int64_t *shapes_host,
+                        const int64_t *lsi_host, void *stream);
+
 /* ---- replaces box_attn_backward (box_attn.h:56-83, box_attn.cu:74-135) ---------------- */
 int boxattn_bwd_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                     const float *loc, const float *attn, const float *grad_out, int B, int S,
@@ -123,9 +136,11 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
  * B*S*H*C floats).  Only float32 and bfloat16 exist here; float64 uses the plain backward.
- * plan_ready: 0 = the call bins the sample points itself; 1 = `workspace` already holds the plan
- * that a *_fwd_train_* call built for the SAME sampling locations and dimensions (the call then
- * fails with hipErrorInvalidValue if the binned algorithm does not apply).
+ * plan_ready: 0 = the call prepares everything itself; otherwise the value a *_fwd_train_* call
+ * returned in *plan_built for the SAME sampling locations and dimensions -- 1: `workspace` holds
+ * the binning plan, 2: it holds the query-grid tile boxes (bf16 box attention in the encoder
+ * case, Lq == S: no global binning at all).  A plan the backward cannot use
+ * (operands the fast paths reject) is ignored and the call falls back.
  * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`; with
  * boxattn_set_variant(6) the point-gradient kernel runs on a library-owned low-priority helper
  * stream (one per device, created on first use) that is forked from and joined back into
@@ -232,9 +247,28 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
  *   6 = like 0 but the helper stream is used (point gradients next to binning / accumulate,
  *       binning next to the training forward).  0 behaves like 4: measured faster for both
  *       storage types.
+ *   7 = like 0 without the query-grid forward kernel (row gathers also in the encoder case),
+ *   8 = like 0 without the query-grid backward (the binned backward also in the encoder case).
  * Returns the previous value.
  */
 int boxattn_set_variant(int variant);
+
+/*
+ * Tuning options for A/B runs (process-wide, relaxed atomics; 0 = default).  Returns the
+ * previous value, -1 for an unknown key.
+ *   0  query-grid kernels, queries per tile: 1 = 16 x 8, 2 = 8 x 8
+ *   1  query-grid kernels, LDS rows per workgroup for the value windows
+ *   2  query-grid kernels, cap of the data-driven window margin (pixels)
+ *   3  query-grid kernels, fixed window margin in 1/16 query-level pixels (0 = data-driven)
+ *   4  query-grid kernels, timing ablations (wrong results): 1 no compute, 2 no staging
+ *   5  query-grid backward: target records per work item (default 512)
+ *   6  query-grid forward: 1 = use the LDS-tiled forward kernel (default off: measured slower)
+ *   7  query-grid backward, timing ablations (wrong results): 1 no rounds, 2 no candidates, 4 no scan
+ *   8  query-grid backward: persistent waves per XCD (default 384)
+ *   9  query-grid backward: 1 = use it for bf16 box attention with Lq == S (default off: measured
+ *      slower than the binned backward)
+ */
+int boxattn_set_option(int key, int value);
 
 /*
  * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the

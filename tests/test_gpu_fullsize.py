@@ -3,11 +3,12 @@ the training entry points the bench times (``*_forward_train`` + ``*_backward(pl
 C ABI's ``*_fwd_train_*`` / ``*_bwd_ws_*``), ALL outputs compared element-wise with the CPU oracle
 (oracle/boxattn_oracle.c, fp64) on the same inputs.
 
-Check per element: ``|got - want| <= tol * (max(1, rms(want)) + |want|)`` with tol = 1e-4 (fp32
-storage) / 1e-2 (bf16 storage) -- BASELINE.json's tolerances as an absolute + relative bound
-(the absolute part follows the tensor's typical magnitude: an fp32 sum of 64 products of O(100)
-terms cannot be held to 1e-4 absolute, a wrong small element among large ones still fails).
-bf16 runs feed ``randn`` values rounded to bf16; the oracle gets exactly those rounded values.
+Check per element (bench.parity_report, shared with bench.py's parity gate):
+``|got - want| <= tol * (max(1, rms(want)) + |want|)`` with tol = 1e-4 (fp32 tensors) / 1e-2
+(bf16 tensors) -- BASELINE.json's tolerances as an absolute + relative bound (the absolute part
+follows the tensor's typical magnitude: an fp32 sum of 64 products of O(100) terms cannot be held
+to 1e-4 absolute, a wrong small element among large ones still fails).  bf16 runs feed ``randn``
+values rounded to bf16; the oracle gets exactly those rounded values.
 
 Reference test this mirrors: tests/box_attn_test.py:96-159 (forward / backward allclose of the
 CUDA op against the pure-PyTorch formulation).
@@ -18,7 +19,6 @@ import torch
 
 import bench
 from oracle import boxattn_oracle as oc
-from test_gpu_parity import on_cell_edge
 
 pytestmark = pytest.mark.gpu
 
@@ -40,38 +40,22 @@ def check(got, want, tol, what, ignore=None):
 
 
 def run_workload(workload, dtype, family, batch=bench.BATCH):
-    """Training forward + planned backward on the bench inputs -> device outputs, oracle outputs."""
-    from boxer_amd import ops
+    """Training forward + planned backward on the bench inputs -> bench.parity_report rows."""
     inp = bench.make_inputs(workload, dtype, "cuda", family=family, batch=batch, seed=0)
-    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
-                                                  "grad_out"))
-    f64 = lambda t: t.detach().double().cpu().numpy()
-    a = dict(value=f64(v), shapes=sh.cpu().numpy(), lsi=ls.cpu().numpy(), loc=f64(loc),
-             attn=f64(attn), grad_out=f64(go))
-    edge = on_cell_edge(a["loc"], a["shapes"])
-    if inp["kind"] == "box":
-        out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
-        grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
-        torch.cuda.synchronize()
-        want_out = oc.box_attn_forward(a["value"], a["shapes"], a["lsi"], a["loc"], a["attn"])
-        want = oc.box_attn_backward(a["value"], a["shapes"], a["lsi"], a["loc"], a["attn"],
-                                    a["grad_out"])
-        got = [out] + list(grads)
-        exp = [want_out] + list(want)
-        names = ["out", "grad_value", "grad_loc", "grad_attn"]
-    else:
-        lw, gm = inp["level_w"], inp["grad_mask"]
-        (out, mask), plan = ops.instance_attn_forward_train(v, sh, ls, loc, attn, lw, 64)
-        grads = ops.instance_attn_backward(v, sh, ls, loc, attn, lw, go, gm, 64, plan=plan)
-        torch.cuda.synchronize()
-        want_out, want_mask = oc.instance_attn_forward(a["value"], a["shapes"], a["lsi"],
-                                                       a["loc"], a["attn"], f64(lw))
-        want = oc.instance_attn_backward(a["value"], a["shapes"], a["lsi"], a["loc"], a["attn"],
-                                         f64(lw), a["grad_out"], f64(gm))
-        got = [out, mask] + list(grads)
-        exp = [want_out, want_mask] + list(want)
-        names = ["out", "mask_out", "grad_value", "grad_loc", "grad_spatial", "grad_level"]
-    return names, got, exp, edge, plan
+    plans = []
+    from boxer_amd import ops
+    orig = ops._forward_train
+
+    def spy(*a, **k):                       # the plan the training forward hands to the backward
+        plans.append(orig(*a, **k))
+        return plans[-1]
+    ops._forward_train = spy
+    try:
+        out, grads = bench.make_step(inp)()
+    finally:
+        ops._forward_train = orig
+    torch.cuda.synchronize()
+    return bench.parity_report(inp, out, grads), plans[-1]
 
 
 CASES = [
@@ -91,12 +75,12 @@ CASES = [
 @pytest.mark.parametrize("workload,dtype,family", CASES,
                          ids=["%s-%s-%s" % (w, str(d).split(".")[-1], f) for w, d, f in CASES])
 def test_bench_workload_matches_oracle(workload, dtype, family):
-    names, got, exp, edge, plan = run_workload(workload, dtype, family)
+    report, plan = run_workload(workload, dtype, family)
     assert plan is not None, "the training forward did not build a backward plan"
-    for name, g, e in zip(names, got, exp):
-        storage = name in ("out", "mask_out", "grad_value")
-        tol = TOL[dtype] if storage else max(TOL[torch.float32], TOL[dtype] * 1e-2)
-        check(g, e, tol, "%s %s" % (workload, name), ignore=edge if name == "grad_loc" else None)
+    assert len(report) >= 4
+    for name, worst, tol in report:
+        assert worst <= tol, "%s %s: worst |err| / (max(1, rms) + |want|) = %.3e > %.0e" % (
+            workload, name, worst, tol)
 
 
 def test_bench_check_gate_catches_a_wrong_tensor():

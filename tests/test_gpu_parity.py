@@ -795,3 +795,111 @@ def test_functions_use_the_plan_and_match():
                                    g["level_w"], g["grad_out"], g["grad_mask"])
     close(v.grad, wi[0], torch.float32, "instance grad_value")
     close(sw.grad, wi[2].reshape(sw.shape), torch.float32, "instance grad_spatial")
+
+
+# ------------------------------------------------------------------ query-grid (encoder) kernels
+def _grid_inputs(levels, dtype, family, batch=2, seed=0):
+    """Encoder-shaped inputs (one query per pixel) from bench.make_inputs on a custom map."""
+    import bench
+    bench.WORKLOADS["_T"] = (levels, "S", 4, "box")
+    try:
+        return bench.make_inputs("_T", dtype, "cuda", family=family, batch=batch, seed=seed)
+    finally:
+        del bench.WORKLOADS["_T"]
+
+
+GRID_LEVELS = [
+    [(37, 53), (19, 27), (10, 14), (5, 7)],        # 4 levels, ragged tiles on every level
+    [(64, 48), (32, 24)],                          # 2 levels (the BEV encoder's geometry)
+    [(16, 16), (8, 8), (4, 4), (1, 3)],            # whole levels inside one tile, a 1-row level
+]
+
+
+@pytest.mark.parametrize("shape_opt", [0, 1, 2])
+@pytest.mark.parametrize("family", ["model", "test"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("levels", GRID_LEVELS, ids=["4lv", "2lv", "tiny"])
+def test_query_grid_forward(levels, dtype, family, shape_opt):
+    """Lq == S: the forward runs the LDS-tiled query-grid kernel (boxattn_tile.h).  Same result as
+    the row-gather kernel (variant 7) and as the oracle, for local windows ("model": rows from
+    LDS) and for uniformly random locations ("test": nearly every point takes the global path)."""
+    import bench
+    from boxer_amd import _lib, ops
+    inp = _grid_inputs(levels, dtype, family)
+    v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
+    old = _lib.set_option("tile_shape", shape_opt)
+    _lib.set_option("tile_fwd", 1)
+    try:
+        out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+        _lib.set_variant(7)
+        ref = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("tile_shape", old)
+        _lib.set_option("tile_fwd", 0)
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    want = oc.box_attn_forward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn))
+    close(out, want, dtype, "out vs oracle")
+    close(out, f64(ref), dtype, "out vs row-gather kernel")
+    if dtype == torch.float32:
+        assert (out - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_query_grid_forward_small_budget_and_margin():
+    """Windows that do not fit (tiny LDS budget) or a margin cap of 1 pixel: the affected points
+    take the global path, results unchanged."""
+    from boxer_amd import _lib, ops
+    inp = _grid_inputs(GRID_LEVELS[0], torch.bfloat16, "model")
+    v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    want = oc.box_attn_forward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn))
+    for name, val in (("tile_rows", 40), ("tile_rows", 2), ("tile_margin_cap", 1)):
+        old = _lib.set_option(name, val)
+        _lib.set_option("tile_fwd", 1)
+        try:
+            out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option(name, old)
+            _lib.set_option("tile_fwd", 0)
+        close(out, want, torch.bfloat16, "out (%s=%d)" % (name, val))
+
+
+@pytest.mark.parametrize("target", [0, 64, 2048])
+@pytest.mark.parametrize("family", ["model", "test"])
+@pytest.mark.parametrize("levels", GRID_LEVELS, ids=["4lv", "2lv", "tiny"])
+def test_query_grid_backward(levels, family, target):
+    """Lq == S, bf16 storage: grad_value comes from the query-grid backward (boxattn_qgrid.h: tile
+    boxes -> candidate enumeration -> MFMA rounds; no global binning).  Compared with the oracle
+    and with the binned backward (variant 8), with and without the training forward's plan, for
+    several work-item sizes (target records per item: split blocks with partial tiles / groups
+    of 2 and 4 blocks)."""
+    from boxer_amd import _lib, ops
+    inp = _grid_inputs(levels, torch.bfloat16, family)
+    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
+                                                  "grad_out"))
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    want = oc.box_attn_backward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn),
+                                f64(go))
+    old = _lib.set_option("qg_target", target)
+    _lib.set_option("qg_bwd", 1)
+    try:
+        out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+        assert plan is not None and plan.kind == 2
+        with_plan = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
+        no_plan = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+        _lib.set_variant(8)
+        binned = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("qg_target", old)
+        _lib.set_option("qg_bwd", 0)
+    for got, name in ((with_plan, "plan"), (no_plan, "no plan")):
+        close(got[0], want[0], torch.bfloat16, "grad_value (%s)" % name)
+        close(got[1], want[1], torch.float32, "grad_loc (%s)" % name,
+              ignore=on_cell_edge(f64(loc), sh.cpu().numpy()))
+        close(got[2], want[2], torch.float32, "grad_attn (%s)" % name)
+    # same sums as the binned backward up to the fp32 order inside a block + one bf16 rounding
+    d = (with_plan[0].float() - binned[0].float()).abs().max().item()
+    assert d <= 2e-2 * max(1.0, binned[0].float().abs().max().item())
+    assert torch.equal(with_plan[0], no_plan[0])          # deterministic: no atomics anywhere
