@@ -13,8 +13,9 @@ features (N(0,1)), positional embeddings, matcher / criterion (a dummy regressio
 class and box heads).  One process per GPU; gradients are all-reduced by DistributedDataParallel
 (RCCL with backend "nccl", gloo in the CPU test) -- the operator itself never communicates.
 
-  python bench_train.py [--steps 10 --warmup 3 --dtype bf16|fp32 --fused-grid]
-  python -m torch.distributed.run --nproc-per-node N bench_train.py --gpus N
+  python bench_train.py [--steps 10 --warmup 3 --dtype bf16|fp32 --fused-grid --fused-pointwise
+                         --model 2d|3d --mask-decoder]
+  python bench_train.py --gpus N          (starts its own N ranks; or under torch.distributed.run)
 prints ONE JSON line on rank 0: ms per step (MAX over ranks), images/s, operator share.
 """
 import argparse
@@ -27,96 +28,72 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 LEVELS_COCO = [(100, 167), (50, 84), (25, 42), (13, 21)]        # 1333x800 at strides 8..64
+LEVELS_BEV = [(234, 234), (117, 117)]                           # Waymo 468 x 468 pillars, neck strides 2, 2
 
 
-class EncoderLayer(nn.Module):
-    """Post-norm: x = LN(x + BoxAttention(x + pos, x)); x = LN(x + FFN(x))."""
+class SyntheticBoxeR(nn.Module):
+    """Encoder + decoder stacks of boxer_amd.layers (the reference's layer classes, pinned by the
+    G8 goldens) on synthetic features.  model "2d": BoxeR-2D detection (or, with ``use_mask``,
+    instance segmentation: InstanceAttention 14 x 14 in the decoder); "3d": BoxeR-3D on a BEV
+    map (Box3dAttention: 8 fixed per-head angles in the encoder, learned rotation in the
+    decoder; box3d_transformer.py)."""
 
-    def __init__(self, attn_cls, d_model, n_head, n_level, d_ffn):
+    def __init__(self, levels, model="2d", d_model=256, n_head=8, d_ffn=1024, n_enc=6, n_dec=6,
+                 n_query=300, n_class=91, use_mask=False):
         super().__init__()
-        self.self_attn = attn_cls(d_model, n_level, n_head)
-        self.linear1, self.linear2 = nn.Linear(d_model, d_ffn), nn.Linear(d_ffn, d_model)
-        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
-
-    def forward(self, src, pos, shapes, mask, lsi, ratios, ref_windows):
-        src = self.norm1(src + self.self_attn(src + pos, src, shapes, mask, lsi, ratios,
-                                              ref_windows)[0])
-        return self.norm2(src + self.linear2(F.relu(self.linear1(src))))
-
-
-class DecoderLayer(nn.Module):
-    """Self-attention over the object queries, box cross-attention into the memory, FFN.
-    With `mask_cls` (InstanceAttention, kernel 14: the instance-segmentation decoder,
-    box_transformer.py:381-384) the cross-attention also returns the per-point RoI features,
-    which are handed back so that their branch takes part in the backward."""
-
-    def __init__(self, attn_cls, d_model, n_head, n_level, d_ffn, mask_cls=None):
-        super().__init__()
-        self.self_attn = nn.MultiheadAttention(d_model, n_head)
-        self.use_mask = mask_cls is not None
-        if self.use_mask:
-            self.cross_attn = mask_cls(d_model, n_level, n_head, 14)
-            self.cross_attn.inferencing = False
+        from boxer_amd import layers
+        self.levels, self.model, self.use_mask = levels, model, use_mask
+        nl = len(levels)
+        if model == "2d":
+            self.encoder = nn.ModuleList(layers.BoxTransformerEncoderLayer(
+                d_model, n_head, nl, d_ffn, 0.0, "relu") for _ in range(n_enc))
+            self.decoder = nn.ModuleList(layers.BoxTransformerDecoderLayer(
+                d_model, n_head, nl, d_ffn, 0.0, "relu", use_mask, "v1") for _ in range(n_dec))
+            for layer in self.decoder:
+                layer.inferencing = False
+                layer.multihead_attn.inferencing = False
+            ref_dim = 4
         else:
-            self.cross_attn = attn_cls(d_model, n_level, n_head)
-        self.linear1, self.linear2 = nn.Linear(d_model, d_ffn), nn.Linear(d_ffn, d_model)
-        self.norm1, self.norm2, self.norm3 = (nn.LayerNorm(d_model) for _ in range(3))
-
-    def forward(self, tgt, query_pos, memory, shapes, mask, lsi, ratios, ref_windows):
-        qk = (tgt + query_pos).transpose(0, 1)
-        tgt = self.norm1(tgt + self.self_attn(qk, qk, tgt.transpose(0, 1))[0].transpose(0, 1))
-        res = self.cross_attn(tgt + query_pos, memory, shapes, mask, lsi, ratios, ref_windows)
-        tgt = self.norm2(tgt + res[0])
-        tgt = self.norm3(tgt + self.linear2(F.relu(self.linear1(tgt))))
-        return (tgt, res[1]) if self.use_mask else (tgt, None)
-
-
-class SyntheticBoxeR2D(nn.Module):
-    def __init__(self, attn_cls, levels, d_model=256, n_head=8, d_ffn=1024, n_enc=6, n_dec=6,
-                 n_query=300, n_class=91, mask_cls=None):
-        super().__init__()
-        self.levels = levels
-        n_level = len(levels)
-        self.encoder = nn.ModuleList(EncoderLayer(attn_cls, d_model, n_head, n_level, d_ffn)
-                                     for _ in range(n_enc))
-        self.decoder = nn.ModuleList(DecoderLayer(attn_cls, d_model, n_head, n_level, d_ffn, mask_cls)
-                                     for _ in range(n_dec))
-        self.roi_head = nn.Linear(d_model, 1) if mask_cls is not None else None
+            self.encoder = nn.ModuleList(layers.Box3dTransformerEncoderLayer(
+                d_model, n_head, nl, d_ffn, 0.0, "relu") for _ in range(n_enc))
+            self.decoder = nn.ModuleList(layers.Box3dTransformerDecoderLayer(
+                d_model, n_head, nl, d_ffn, 0.0, "relu") for _ in range(n_dec))
+            ref_dim = 7
+        self.roi_head = nn.Linear(d_model, 1) if use_mask else None
         self.query_embed = nn.Embedding(n_query, d_model)
         self.query_pos = nn.Embedding(n_query, d_model)
-        self.query_ref = nn.Embedding(n_query, 4)                 # logits of (cx, cy, w, h)
+        self.query_ref = nn.Embedding(n_query, ref_dim)           # logits of (cx, cy, w, h[, angle, ..])
         self.class_head, self.box_head = nn.Linear(d_model, n_class), nn.Linear(d_model, 4)
         shapes = torch.tensor(levels, dtype=torch.long)
         self.register_buffer("shapes", shapes)
         self.register_buffer("lsi", torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1])))
-        self.register_buffer("enc_ref", self._pixel_windows(levels))
+        if model == "2d":
+            self.register_buffer("enc_ref", layers.encoder_ref_windows_2d(levels, 1)[0])
+        else:
+            self.register_buffer("enc_ref", layers.encoder_ref_windows_3d(levels, 1)[0])
 
-    @staticmethod
-    def _pixel_windows(levels, ref_size=4.0):
-        """One window per pixel of every level, centred on it, ref_size pixels wide
-        (box_transformer.py:70-116 without padding)."""
-        out = []
-        for (h, w) in levels:
-            ys = (torch.arange(1, h + 1, dtype=torch.float32) - 0.5) / h
-            xs = (torch.arange(1, w + 1, dtype=torch.float32) - 0.5) / w
-            cy, cx = torch.meshgrid(ys, xs, indexing="ij")
-            size = torch.tensor([ref_size / w, ref_size / h]).expand(h * w, 2)
-            out.append(torch.cat([cx.reshape(-1, 1), cy.reshape(-1, 1), size], dim=1))
-        return torch.cat(out, dim=0)
+    def attention_modules(self):
+        from boxer_amd import modules
+        return [m for m in self.modules() if isinstance(m, modules._BoxAttentionBase)]
 
     def forward(self, src, pos):
         b = src.size(0)
-        args = (self.shapes, None, self.lsi, None)
         memory = src
-        enc_ref = self.enc_ref[None].expand(b, -1, -1)
-        for layer in self.encoder:
-            memory = layer(memory, pos, *args, enc_ref)
+        enc_ref = self.enc_ref[None].expand(b, *self.enc_ref.shape)
         tgt = self.query_embed.weight[None].expand(b, -1, -1)
         qpos = self.query_pos.weight[None].expand(b, -1, -1)
         ref = self.query_ref.weight.sigmoid()[None].expand(b, -1, -1)
         roi = None
-        for layer in self.decoder:
-            tgt, roi = layer(tgt, qpos, memory, *args, ref)
+        if self.model == "2d":
+            for layer in self.encoder:
+                memory = layer(memory, pos, self.shapes, None, self.lsi, None, enc_ref)
+            for layer in self.decoder:
+                tgt, roi = layer(tgt, qpos, memory, self.shapes, None, self.lsi, None, ref)
+        else:
+            for layer in self.encoder:
+                memory = layer(memory, pos, self.shapes, self.lsi, enc_ref)
+            for layer in self.decoder:
+                tgt = layer(tgt, qpos, memory, self.shapes, self.lsi, ref)
         logits, boxes = self.class_head(tgt), self.box_head(tgt).sigmoid()
         if roi is not None:                       # (B, Lq, 14, 14, d) -> mask logits (B, Lq, 14, 14)
             return logits, boxes, self.roi_head(roi).squeeze(-1)
@@ -156,12 +133,23 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
                     help="bf16: autocast for the dense layers + the operator's native bf16 mode")
     ap.add_argument("--fused-grid", action="store_true")
+    ap.add_argument("--fused-pointwise", action="store_true",
+                    help="softmax and value mask + cast as single HIP passes (module.fused_pointwise)")
     ap.add_argument("--mask-decoder", action="store_true",
                     help="InstanceAttention (14x14) in the decoder: the instance-segmentation model")
-    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--layers", type=int, default=None, help="encoder = decoder layers (2d: 6, 3d: 2)")
+    ap.add_argument("--model", default="2d", choices=["2d", "3d"],
+                    help="3d: BoxeR-3D on a 234^2 + 117^2 BEV map (BASELINE configs[4])")
     args = ap.parse_args()
+    if args.layers is None:
+        args.layers = 6 if args.model == "2d" else 2
 
-    from boxer_amd import BoxAttention, InstanceAttention, _lib
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # start our own ranks (bench.spawn_ranks)
+        import sys
+        import bench
+        sys.exit(bench.spawn_ranks(args.gpus, cmd=[sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
+    from boxer_amd import _lib
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,19 +163,20 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     torch.manual_seed(0)                                     # same initial weights on all ranks
-    model = SyntheticBoxeR2D(BoxAttention, LEVELS_COCO, n_enc=args.layers, n_dec=args.layers,
-                             mask_cls=InstanceAttention if args.mask_decoder else None).to(device)
-    for m in model.modules():
-        if isinstance(m, (BoxAttention, InstanceAttention)):
-            m.native_bf16 = args.dtype == "bf16"
-            m.fused_grid = args.fused_grid
-            with torch.no_grad():                            # trained-like box offsets
-                m.linear_box_weight.normal_(0, 0.02)
+    levels = LEVELS_COCO if args.model == "2d" else LEVELS_BEV
+    model = SyntheticBoxeR(levels, args.model, n_enc=args.layers, n_dec=args.layers,
+                           use_mask=args.mask_decoder and args.model == "2d").to(device)
+    for m in model.attention_modules():
+        m.native_bf16 = args.dtype == "bf16"
+        m.fused_grid = args.fused_grid
+        m.fused_pointwise = args.fused_pointwise
+        with torch.no_grad():                                # trained-like box offsets
+            m.linear_box_weight.normal_(0, 0.02)
     n_params = sum(p.numel() for p in model.parameters())
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
-    batch = make_batch(LEVELS_COCO, args.batch, 256, device, seed=100 + rank)
+    batch = make_batch(levels, args.batch, 256, device, seed=100 + rank)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
 
     for _ in range(args.warmup):
@@ -215,10 +204,11 @@ def main():
 
     if rank == 0:
         print(json.dumps({
-            "metric": "synthetic BoxeR-2D training step (6+6 layers, COCO 1333x800 shapes)",
+            "metric": "synthetic BoxeR-%s training step (%d+%d layers, levels %s)" % (
+                args.model.upper(), args.layers, args.layers, "/".join("%dx%d" % hw for hw in levels)),
             "ms_per_step": round(ms_step, 3), "images_per_s": round(world * args.batch / ms_step * 1e3, 2),
             "n_gpus": world, "batch_per_gpu": args.batch, "dtype": args.dtype,
-            "fused_grid": args.fused_grid, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
+            "fused_grid": args.fused_grid, "fused_pointwise": args.fused_pointwise, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
             "operator_kernels_ms_per_step": round(op_ms, 3),
             "operator_share": round(op_ms / ms_step, 3), "loss": round(float(loss), 4),
             "data": "synthetic", "scaling": "weak"}), flush=True)

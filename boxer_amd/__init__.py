@@ -12,12 +12,14 @@ DESIGN.md and INTEGRATION.md.  There is no CPU fallback: ops raise if the librar
 """
 from . import _lib, ops
 from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
-                        InstanceAttnBF16Function, InstanceAttnFunction)
+                        InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
+                        ValueMaskCastFunction)
 from .modules import Box3dAttention, BoxAttention, InstanceAttention
 
 __all__ = [
     "ops", "BoxAttnFunction", "InstanceAttnFunction", "BoxAttnBF16Function",
-    "InstanceAttnBF16Function", "BoxGridFunction", "BoxAttention", "InstanceAttention", "Box3dAttention",
+    "InstanceAttnBF16Function", "BoxGridFunction", "LogitSoftmaxFunction", "ValueMaskCastFunction",
+    "BoxAttention", "InstanceAttention", "Box3dAttention",
     "build", "build_info",
 ]
 __version__ = "0.1.0"

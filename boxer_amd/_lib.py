@@ -41,6 +41,15 @@ _HL_SIGNATURES = {
     # forward args + shapes_host, lsi_host, stream
     "boxattn_fwd_hl": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp],
 }
+_ll = ctypes.c_longlong
+_POINTWISE_SIGNATURES = {
+    "boxattn_softmax_fwd_f32": [_vp, _ll, _i, _vp, _vp],
+    "boxattn_softmax_fwd_bf16": [_vp, _ll, _i, _vp, _vp],
+    "boxattn_softmax_bwd_f32": [_vp, _vp, _ll, _i, _vp, _vp],
+    "boxattn_softmax_bwd_bf16": [_vp, _vp, _ll, _i, _vp, _vp],
+    "boxattn_value_prep_f32": [_vp, _vp, _ll, _i, _vp, _vp],
+    "boxattn_value_prep_bf16": [_vp, _vp, _ll, _i, _vp, _vp],
+}
 _GRID_SIGNATURES = {
     # ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios, [grad_grid,]
     # B, Lq, H, L, P, outputs..., stream
@@ -48,7 +57,7 @@ _GRID_SIGNATURES = {
     "boxattn_grid_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp],
 }
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "boxattn_set_option",
-           "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16",
+           "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16", *sorted(_POINTWISE_SIGNATURES),
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
@@ -123,7 +132,7 @@ def load():
             fn.restype = _i
     lib.boxattn_set_option.argtypes = [_i, _i]
     lib.boxattn_set_option.restype = _i
-    for name, args in _GRID_SIGNATURES.items():
+    for name, args in list(_GRID_SIGNATURES.items()) + list(_POINTWISE_SIGNATURES.items()):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = _i
     lib.boxattn_bwd_workspace_bytes.argtypes = [_i] * 8 + [_vp, _vp]

@@ -1392,4 +1392,85 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
     return finish();
 }
 
+
+}  // extern "C"
+
+// ---- pointwise work around the operator ---------------------------------
+template <typename T>
+static int softmax_fwd(const T *logits, long long rows, int n, float *attn, hipStream_t st)
+{
+    if (rows < 0 || n <= 0 || n > 64) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    if (!logits || !attn) return (int)hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    if (n <= 16)
+        hipLaunchKernelGGL((softmax_rows_fwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, logits,
+                           (size_t)rows, n, attn);
+    else
+        hipLaunchKernelGGL((softmax_rows_fwd_kernel<T, 64>), dim3(blocks), dim3(256), 0, st, logits,
+                           (size_t)rows, n, attn);
+    return finish();
+}
+template <typename T>
+static int softmax_bwd(const float *attn, const float *grad_attn, long long rows, int n,
+                       T *grad_logits, hipStream_t st)
+{
+    if (rows < 0 || n <= 0 || n > 64) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    if (!attn || !grad_attn || !grad_logits) return (int)hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    if (n <= 16)
+        hipLaunchKernelGGL((softmax_rows_bwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, attn,
+                           grad_attn, (size_t)rows, n, grad_logits);
+    else
+        hipLaunchKernelGGL((softmax_rows_bwd_kernel<T, 64>), dim3(blocks), dim3(256), 0, st, attn,
+                           grad_attn, (size_t)rows, n, grad_logits);
+    return finish();
+}
+
+template <typename T>
+static int value_prep(const T *value, const unsigned char *mask, long long rows, int d,
+                      uint16_t *out, hipStream_t st)
+{
+    if (rows < 0 || d <= 0 || d % 8 != 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    if (!value || !out || !aligned(value, 16) || !aligned(out, 16)) return (int)hipErrorInvalidValue;
+    const size_t n8 = (size_t)rows * d / 8;
+    hipLaunchKernelGGL((value_mask_cast_kernel<T>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0,
+                       st, value, mask, (size_t)rows, d, out);
+    return finish();
+}
+
+extern "C" {
+
+int boxattn_softmax_fwd_f32(const float *logits, long long rows, int n, float *attn, void *stream)
+{
+    return softmax_fwd<float>(logits, rows, n, attn, (hipStream_t)stream);
+}
+int boxattn_softmax_fwd_bf16(const uint16_t *logits, long long rows, int n, float *attn, void *stream)
+{
+    return softmax_fwd<bf16_t>(logits, rows, n, attn, (hipStream_t)stream);
+}
+int boxattn_softmax_bwd_f32(const float *attn, const float *grad_attn, long long rows, int n,
+                            float *grad_logits, void *stream)
+{
+    return softmax_bwd<float>(attn, grad_attn, rows, n, grad_logits, (hipStream_t)stream);
+}
+int boxattn_softmax_bwd_bf16(const float *attn, const float *grad_attn, long long rows, int n,
+                             uint16_t *grad_logits, void *stream)
+{
+    return softmax_bwd<bf16_t>(attn, grad_attn, rows, n, grad_logits, (hipStream_t)stream);
+}
+
+int boxattn_value_prep_f32(const float *value, const unsigned char *mask, long long rows, int d,
+                           uint16_t *out, void *stream)
+{
+    return value_prep<float>(value, mask, rows, d, out, (hipStream_t)stream);
+}
+int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, long long rows, int d,
+                            uint16_t *out, void *stream)
+{
+    return value_prep<bf16_t>(value, mask, rows, d, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -138,4 +138,92 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Pointwise work around the operator (reference e2edet/module/box_attention.py:222-231),
+// SURVEY.md 8(f) N3:
+//   * attention weights = softmax over the L*P logits of a (query, head), computed in float32
+//     whatever the logits' type (float32 or the bfloat16 of an autocast projection) -- one pass
+//     instead of cast + softmax (+ cast); its backward grad_logits = a (g - sum_j a_j g_j),
+//     written in the logits' type;
+//   * value rows of padded pixels (v_mask) zeroed and cast to bfloat16 in the same pass
+//     (`value.masked_fill(v_mask[..., None], 0)` followed by the op's bf16 conversion).
+// One thread per row; N = L*P is small (16 for BoxeR's 2x2 grids on 4 levels), a row is one or
+// two cache lines, neighbouring threads read neighbouring rows.
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float pw_ld(const T *p);
+template <> __device__ __forceinline__ float pw_ld<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float pw_ld<bf16_t>(const bf16_t *p) { return bf16_bits_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void pw_st(T *p, float v);
+template <> __device__ __forceinline__ void pw_st<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void pw_st<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+
+template <typename T, int NMAX>      // n <= NMAX: the row stays in registers
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const T *__restrict__ logits,
+                                                               size_t rows, int n,
+                                                               float *__restrict__ attn)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const T *src = logits + r * (size_t)n;
+    float *dst = attn + r * (size_t)n;
+    float v[NMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        v[i] = i < n ? pw_ld<T>(src + i) : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        v[i] = i < n ? __expf(v[i] - m) : 0.f;
+        sum += v[i];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+        if (i < n) dst[i] = v[i] * inv;
+}
+
+template <typename T, int NMAX>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__restrict__ attn,
+                                                               const float *__restrict__ grad_attn,
+                                                               size_t rows, int n,
+                                                               T *__restrict__ grad_logits)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *a = attn + r * (size_t)n, *g = grad_attn + r * (size_t)n;
+    T *dst = grad_logits + r * (size_t)n;
+    float av[NMAX], gv[NMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        av[i] = i < n ? a[i] : 0.f;
+        gv[i] = i < n ? g[i] : 0.f;
+        dot += av[i] * gv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i)
+        if (i < n) pw_st<T>(dst + i, av[i] * (gv[i] - dot));
+}
+
+// value (rows, d) of type T -> bfloat16, rows with mask != 0 zeroed; 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void value_mask_cast_kernel(const T *__restrict__ value,
+                                                              const unsigned char *__restrict__ mask,
+                                                              size_t rows, int d,
+                                                              bf16_t *__restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= rows * (size_t)d) return;
+    const size_t r = i / (unsigned)d;
+    const bool dead = mask && mask[r];
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = dead ? 0.f : pw_ld<T>(value + i + k);
+    VecIO<bf16_t, 8>::st(out + i, v);
+}
+
 }  // namespace boxattn

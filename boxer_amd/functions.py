@@ -186,3 +186,42 @@ class BoxGridFunction(Function):
             n = min(5, ref_windows.size(-1))
             grad_ref[..., :n] = rows[..., :n]
         return grad_ref, grad_offsets, None, None, None
+
+
+class LogitSoftmaxFunction(Function):
+    """softmax over the last axis in float32 (``module.fused_pointwise``): one HIP pass each way
+    instead of autocast's cast + softmax (+ cast back); see ``ops.softmax_forward``."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = logits.contiguous()
+        attn = ops.softmax_forward(logits)
+        ctx.save_for_backward(attn)
+        ctx.logits_dtype = logits.dtype
+        return attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_attn):
+        (attn,) = ctx.saved_tensors
+        return ops.softmax_backward(attn, grad_attn.contiguous().float(), ctx.logits_dtype)
+
+
+class ValueMaskCastFunction(Function):
+    """value -> bfloat16 with padded rows zeroed (``ops.value_mask_cast``); the gradient is the
+    upstream one with the same rows zeroed, in the input's type."""
+
+    @staticmethod
+    def forward(ctx, value, v_mask):
+        ctx.save_for_backward(v_mask)
+        ctx.value_dtype = value.dtype
+        return ops.value_mask_cast(value.contiguous(), v_mask)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        (v_mask,) = ctx.saved_tensors
+        grad = grad.to(ctx.value_dtype)
+        if v_mask is not None:
+            grad = grad.masked_fill(v_mask[..., None], 0)
+        return grad, None

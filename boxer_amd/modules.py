@@ -21,8 +21,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
-                        InstanceAttnBF16Function,
-                        InstanceAttnFunction)
+                        InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
+                        ValueMaskCastFunction)
 
 
 def _kernel_offsets(kernel_size, divisor):
@@ -50,6 +50,9 @@ class _BoxAttentionBase(nn.Module):
         self.native_bf16 = False
         # opt-in: box -> grid expansion in one HIP kernel each way (BoxGridFunction)
         self.fused_grid = False
+        # opt-in: the softmax over the L*P logits and, in the bf16 storage mode, the value
+        # mask-fill + bf16 cast as single HIP passes (LogitSoftmaxFunction, ValueMaskCastFunction)
+        self.fused_pointwise = False
 
         self.linear_box_weight = nn.Parameter(torch.zeros(num_level * num_head * box_vars, d_model))
         self.linear_box_bias = nn.Parameter(torch.zeros(num_head * num_level * box_vars))
@@ -74,9 +77,19 @@ class _BoxAttentionBase(nn.Module):
     def _project_value(self, value, v_mask):
         b, s = value.shape[:2]
         value = self.value_proj(value)
-        if v_mask is not None:
+        if (self.fused_pointwise and self.native_bf16 and value.is_cuda and
+                value.dtype in (torch.float32, torch.bfloat16) and self.d_model % 8 == 0):
+            value = ValueMaskCastFunction.apply(value, v_mask)
+        elif v_mask is not None:
             value = value.masked_fill(v_mask[..., None], float(0))
         return value.view(b, s, self.num_head, self.head_dim)
+
+    def _softmax(self, logits):
+        """softmax over the last axis (the L * P logits of a (query, head))."""
+        if (self.fused_pointwise and logits.is_cuda and logits.size(-1) <= 64 and
+                logits.dtype in (torch.float32, torch.bfloat16)):
+            return LogitSoftmaxFunction.apply(logits)
+        return F.softmax(logits, dim=-1)
 
     def _box_offsets(self, query, ref_windows, n_vars):
         b, l = ref_windows.shape[:2]
@@ -133,7 +146,7 @@ class BoxAttention(_BoxAttentionBase):
     def _softmax_weights(self, query):
         b, l1 = query.shape[:2]
         w = F.linear(query, self.linear_attn_weight, self.linear_attn_bias)
-        w = F.softmax(w.view(b, l1, self.num_head, -1), dim=-1)
+        w = self._softmax(w.view(b, l1, self.num_head, -1))
         return w.view(b, l1, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
 
     def forward(self, query, value, v_shape, v_mask, v_start_index, v_valid_ratios, ref_windows):

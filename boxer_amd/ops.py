@@ -345,3 +345,55 @@ def box_grid_backward(ref_windows, offsets, kernel_indices, valid_ratios, angle_
                kernel_indices, valid_ratios if valid_ratios is not None else 0, grad_grid, *dims,
                grad_offsets, grad_rows if grad_rows is not None else 0)
     return grad_offsets, grad_rows
+
+
+# ---------------------------------------------------------------------------------------
+# pointwise work around the operator (opt-in)
+# ---------------------------------------------------------------------------------------
+def _pw_suffix(t, what):
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.bfloat16:
+        return "bf16"
+    raise RuntimeError("%s: float32 or bfloat16 expected, got %s" % (what, t.dtype))
+
+
+def softmax_forward(logits):
+    """softmax over the last axis (the L*P logits of a (query, head); at most 64) of float32 /
+    bfloat16 ``logits`` -> float32 weights, one pass (box_attention.py:227-229)."""
+    _check(logits, "logits")
+    n = logits.size(-1)
+    rows = logits.numel() // max(n, 1)
+    attn = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    _grid_call("boxattn_softmax_fwd_" + _pw_suffix(logits, "logits"), logits, logits, rows, n, attn)
+    return attn
+
+
+def softmax_backward(attn, grad_attn, dtype):
+    """-> grad_logits = attn * (grad_attn - sum(attn * grad_attn)) in ``dtype``."""
+    _check(attn, "attn")
+    _check(grad_attn, "grad_attn")
+    if attn.dtype != torch.float32 or grad_attn.dtype != torch.float32 or attn.shape != grad_attn.shape:
+        raise RuntimeError("softmax_backward: float32 attn / grad_attn of one shape expected")
+    out = torch.empty(attn.shape, dtype=dtype, device=attn.device)
+    n = attn.size(-1)
+    _grid_call("boxattn_softmax_bwd_" + _pw_suffix(out, "grad_logits"), attn, attn, grad_attn,
+               attn.numel() // max(n, 1), n, out)
+    return out
+
+
+def value_mask_cast(value, v_mask):
+    """(B, S, d) float32 / bfloat16 -> bfloat16 with the rows of padded pixels (``v_mask`` (B, S)
+    bool, or None) zeroed, one pass (box_attention.py:223-225 + the op's bf16 conversion)."""
+    _check(value, "value")
+    d = value.size(-1)
+    rows = value.numel() // max(d, 1)
+    mask = 0
+    if v_mask is not None:
+        _check(v_mask, "v_mask")
+        if v_mask.dtype != torch.bool or v_mask.numel() != rows:
+            raise RuntimeError("v_mask must be a bool tensor with one entry per value row")
+        mask = v_mask
+    out = torch.empty(value.shape, dtype=torch.bfloat16, device=value.device)
+    _grid_call("boxattn_value_prep_" + _pw_suffix(value, "value"), value, value, mask, rows, d, out)
+    return out

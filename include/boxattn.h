@@ -254,6 +254,28 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
 int boxattn_set_variant(int variant);
 
 /*
+ * ---- pointwise work around the operator (opt-in, beyond the reference's native module) ------
+ * The modules' softmax over the L*P attention logits of every (query, head) and the zeroing of
+ * padded value rows (reference e2edet/module/box_attention.py:222-231), as single passes:
+ *   boxattn_softmax_fwd_*: logits (rows, n) float32 / bfloat16 -> attn (rows, n) float32, n <= 64
+ *   boxattn_softmax_bwd_*: grad_logits = attn * (grad_attn - sum_j attn_j grad_attn_j), written
+ *                          in the logits' type
+ *   boxattn_value_prep_*:  value (rows, d) float32 / bfloat16 -> bfloat16 with the rows whose mask
+ *                          byte is non-zero set to 0 (mask may be NULL); d % 8 == 0
+ */
+int boxattn_softmax_fwd_f32(const float *logits, long long rows, int n, float *attn, void *stream);
+int boxattn_softmax_fwd_bf16(const uint16_t *logits, long long rows, int n, float *attn,
+                             void *stream);
+int boxattn_softmax_bwd_f32(const float *attn, const float *grad_attn, long long rows, int n,
+                            float *grad_logits, void *stream);
+int boxattn_softmax_bwd_bf16(const float *attn, const float *grad_attn, long long rows, int n,
+                             uint16_t *grad_logits, void *stream);
+int boxattn_value_prep_f32(const float *value, const unsigned char *mask, long long rows, int d,
+                           uint16_t *out, void *stream);
+int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, long long rows, int d,
+                            uint16_t *out, void *stream);
+
+/*
  * Tuning options for A/B runs (process-wide, relaxed atomics; 0 = default).  Returns the
  * previous value, -1 for an unknown key.
  *   0  query-grid kernels, queries per tile: 1 = 16 x 8, 2 = 8 x 8

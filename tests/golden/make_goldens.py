@@ -386,7 +386,133 @@ def g7():
          shapes=shapes, lsi=lsi, grid=grid, attn=attn, out=out)))
 
 
+# --------------------------------------------------------------------------------------
+# G8: transformer LAYERS around the modules: the reference's
+# BoxTransformerEncoderLayer / DecoderLayer (box_transformer.py:316-465) and the BoxeR-3D
+# Box3dTransformerEncoderLayer / DecoderLayer with the encoder's reference windows of 8 fixed
+# per-head angles (box3d_transformer.py:62-109, 230-322), run on small maps in fp64.
+# --------------------------------------------------------------------------------------
+def load_reference_transformers():
+    import copy
+    box_attention = load_reference_modules()
+    sys.modules["e2edet.module.box_attention"] = box_attention
+    sys.modules["e2edet.module"].__path__ = []            # a package: relative imports resolve
+    general = types.ModuleType("e2edet.utils.general")
+    general.__dict__.update({"torch": torch, "F": F, "math": math, "nn": torch.nn, "copy": copy})
+    _extract(os.path.join(REF, "e2edet/utils/general.py"),
+             ["flatten_with_shape", "inverse_sigmoid", "get_clones", "get_activation_fn",
+              "get_proposal_pos_embed", "normalize_period"], general.__dict__)
+    sys.modules.setdefault("e2edet.utils", types.ModuleType("e2edet.utils"))
+    sys.modules["e2edet.utils.general"] = general
+    mods = []
+    for name in ("box_transformer", "box3d_transformer"):
+        spec = importlib.util.spec_from_file_location(
+            "e2edet.module." + name, os.path.join(REF, "e2edet/module/%s.py" % name))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["e2edet.module." + name] = mod
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    return mods
+
+
+def g8():
+    tr2d, tr3d = load_reference_transformers()
+    d, nh, ff, B, Lq = 32, 4, 48, 2, 6
+
+    def randomise(m, seed):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+
+    def pack(m, extra):
+        sd = {"sd." + k: v for k, v in m.state_dict().items()}
+        sd.update(extra)
+        return sd
+
+    # ---- 2D: encoder layer over a 2-level map with padding mask + valid ratios
+    levels = [(7, 6), (4, 3)]
+    shapes = torch.tensor(levels, dtype=torch.long)
+    lsi = lsi_of(shapes)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(90)
+    src = torch.randn(B, S, d, generator=g)
+    pos = 0.3 * torch.randn(B, S, d, generator=g)
+    mask = torch.rand(B, S, generator=g) < 0.1
+    ratios = 0.7 + 0.3 * torch.rand(B, 1, 1, len(levels), 1, 2, generator=g)
+    enc_ref = torch.rand(B, S, 4, generator=g)
+    enc_ref[..., 2:] = 0.1 + 0.3 * enc_ref[..., 2:]
+    enc = tr2d.BoxTransformerEncoderLayer(d, nh, len(levels), ff, 0.0, "relu").double()
+    randomise(enc, 91)
+    memory = enc(src, pos, shapes, mask, lsi, ratios, enc_ref)
+    save("G8_layer_enc2d", **pack(enc, dict(src=src, pos=pos, v_mask=mask, ratios=ratios,
+         ref_windows=enc_ref, shapes=shapes, lsi=lsi, out=memory)))
+
+    # ---- 2D: decoder layers (detection: BoxAttention; instance segmentation: InstanceAttention
+    #      14x14, training branch, both residual modes)
+    tgt = torch.randn(B, Lq, d, generator=g)
+    qpos = 0.3 * torch.randn(B, Lq, d, generator=g)
+    dec_ref = torch.rand(B, Lq, 4, generator=g)
+    dec_ref[..., 2:] = 0.1 + 0.4 * dec_ref[..., 2:]
+    dec = tr2d.BoxTransformerDecoderLayer(d, nh, len(levels), ff, 0.0, "relu", False, "v1").double()
+    randomise(dec, 92)
+    out, roi = dec(tgt, qpos, memory.detach(), shapes, mask, lsi, ratios, dec_ref)
+    assert roi is None
+    save("G8_layer_dec2d", **pack(dec, dict(tgt=tgt, query_pos=qpos, memory=memory, v_mask=mask,
+         ratios=ratios, ref_windows=dec_ref, shapes=shapes, lsi=lsi, out=out)))
+    for mode in ("v1", "v2"):
+        dec = tr2d.BoxTransformerDecoderLayer(d, nh, len(levels), ff, 0.0, "relu", True, mode).double()
+        randomise(dec, 93)
+        dec.inferencing = False
+        dec.multihead_attn.inferencing = False
+        out, roi = dec(tgt, qpos, memory.detach(), shapes, mask, lsi, ratios, dec_ref)
+        save("G8_layer_dec2d_mask_%s" % mode, **pack(dec, dict(
+            tgt=tgt, query_pos=qpos, memory=memory, v_mask=mask, ratios=ratios,
+            ref_windows=dec_ref, shapes=shapes, lsi=lsi, out=out, roi=roi)))
+
+    # ---- 2D: the encoder's reference windows, with and without padding masks
+    masks = []
+    for (h, w) in levels:
+        m = torch.zeros(B, h, w, dtype=torch.bool)
+        m[0, :, w - 2:] = True                    # image 0: two padded columns
+        m[1, h - 1:, :] = True                    # image 1: one padded row
+        masks.append(m)
+    maps2 = [torch.zeros(B, d, h, w) for h, w in levels]
+    holder2 = types.SimpleNamespace(ref_size=4)
+    rw_masked = tr2d.BoxTransformer._create_ref_windows(holder2, maps2, masks)
+    rw_plain = tr2d.BoxTransformer._create_ref_windows(holder2, maps2, None)
+    save("G8_refwin2d", shapes=shapes, masks=torch.cat([m.flatten(1) for m in masks], 1),
+         ref_masked=rw_masked, ref_plain=rw_plain)
+
+    # ---- 3D (BEV): the encoder's reference windows (8 fixed per-head angles) + one encoder
+    #      layer; one decoder layer with learned rotation
+    nh3 = 8
+    levels3 = [(6, 6), (3, 3)]
+    shapes3 = torch.tensor(levels3, dtype=torch.long)
+    lsi3 = lsi_of(shapes3)
+    S3 = int(shapes3.prod(1).sum())
+    maps = [torch.zeros(B, d, h, w) for h, w in levels3]
+    holder = types.SimpleNamespace(ref_size=4)
+    ref3 = tr3d.Box3dTransformer._create_ref_windows(holder, maps)             # (B, S, 8, 5)
+    src3 = torch.randn(B, S3, d, generator=g)
+    pos3 = 0.3 * torch.randn(B, S3, d, generator=g)
+    enc3 = tr3d.Box3dTransformerEncoderLayer(d, nh3, len(levels3), ff, 0.0, "relu").double()
+    randomise(enc3, 94)
+    mem3 = enc3(src3, pos3, shapes3, lsi3, ref3)
+    save("G8_layer_enc3d", **pack(enc3, dict(src=src3, pos=pos3, ref_windows=ref3, shapes=shapes3,
+         lsi=lsi3, out=mem3)))
+    dec_ref3 = torch.rand(B, Lq, 7, generator=g)
+    dec_ref3[..., 2:4] = 0.1 + 0.4 * dec_ref3[..., 2:4]
+    dec3 = tr3d.Box3dTransformerDecoderLayer(d, nh3, len(levels3), ff, 0.0, "relu").double()
+    randomise(dec3, 95)
+    out3 = dec3(tgt, qpos, mem3.detach(), shapes3, lsi3, dec_ref3)
+    save("G8_layer_dec3d", **pack(dec3, dict(tgt=tgt, query_pos=qpos, memory=mem3,
+         ref_windows=dec_ref3, shapes=shapes3, lsi=lsi3, out=out3)))
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not found (run in the build container)"
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
-        fn()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+        if not only or fn.__name__ in only:
+            fn()

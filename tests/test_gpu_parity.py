@@ -903,3 +903,83 @@ def test_query_grid_backward(levels, family, target):
     d = (with_plan[0].float() - binned[0].float()).abs().max().item()
     assert d <= 2e-2 * max(1.0, binned[0].float().abs().max().item())
     assert torch.equal(with_plan[0], no_plan[0])          # deterministic: no atomics anywhere
+
+
+# ------------------------------------------------------------------ pointwise passes (N3)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n", [4, 16, 36, 64])
+def test_softmax_passes_match_torch(n, dtype):
+    from boxer_amd import LogitSoftmaxFunction
+    g = torch.Generator(device="cuda").manual_seed(n)
+    logits = (3 * torch.randn(3, 50, 8, n, device="cuda", generator=g)).to(dtype).requires_grad_()
+    up = torch.randn(3, 50, 8, n, device="cuda", generator=g)
+    got = LogitSoftmaxFunction.apply(logits)
+    assert got.dtype == torch.float32
+    got.backward(up)
+    ref_in = logits.detach().double().requires_grad_()
+    want = torch.softmax(ref_in, -1)
+    want.backward(up.double())
+    assert (got.double() - want).abs().max().item() <= 1e-6
+    tol = 1e-6 if dtype == torch.float32 else 4e-3            # grad_logits rounded to bf16
+    assert logits.grad.dtype == dtype
+    assert (logits.grad.double() - ref_in.grad).abs().max().item() <= tol * max(
+        1.0, ref_in.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_value_mask_cast_matches_torch(dtype):
+    from boxer_amd import ValueMaskCastFunction
+    g = torch.Generator(device="cuda").manual_seed(3)
+    value = torch.randn(2, 333, 256, device="cuda", generator=g).to(dtype).requires_grad_()
+    mask = torch.rand(2, 333, device="cuda", generator=g) < 0.2
+    for m in (mask, None):
+        got = ValueMaskCastFunction.apply(value, m)
+        want = value.detach().to(torch.bfloat16)
+        if m is not None:
+            want = want.masked_fill(m[..., None], 0)
+        assert got.dtype == torch.bfloat16 and torch.equal(got, want)
+        value.grad = None
+        got.backward(torch.ones_like(got))
+        want_g = torch.ones_like(value)
+        if m is not None:
+            want_g = want_g.masked_fill(m[..., None], 0)
+        assert value.grad.dtype == dtype and torch.equal(value.grad, want_g)
+
+
+def test_modules_with_fused_pointwise():
+    """``module.fused_pointwise``: the softmax / mask + cast passes leave outputs and parameter
+    gradients of the modules unchanged (float32 modules; bf16 storage mode for the value pass)."""
+    from boxer_amd import Box3dAttention, BoxAttention, InstanceAttention
+    torch.manual_seed(0)
+    shapes = torch.tensor([(12, 9), (6, 5)], device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    B, Lq, d = 2, 17, 64
+    query = torch.randn(B, Lq, d, device="cuda")
+    value = torch.randn(B, S, d, device="cuda")
+    v_mask = torch.rand(B, S, device="cuda") < 0.15
+    ref = torch.rand(B, Lq, 5, device="cuda") * 0.5 + 0.2
+    for cls, kw, native in ((BoxAttention, {}, False), (BoxAttention, {}, True),
+                            (Box3dAttention, {"with_rotation": True}, False),
+                            (InstanceAttention, {"kernel_size": 4}, False)):
+        m = cls(d, 2, 8, **kw).cuda()
+        m.native_bf16 = native
+        m.inferencing = False
+        with torch.no_grad():
+            m.linear_box_weight.normal_(0, 0.3)
+            m.linear_attn_weight.normal_(0, 0.3)
+        rw = ref if cls is Box3dAttention else ref[..., :4]
+        outs = []
+        for fused in (False, True):
+            m.fused_pointwise = fused
+            m.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native):
+                res = m(query, value, shapes, v_mask, lsi, None, rw)
+            res[0].float().square().sum().backward()
+            outs.append((res[0].detach().float(),
+                         [p.grad.detach().clone() for p in m.parameters()]))
+        tol = 2e-2 if native else 1e-5
+        scale = max(1.0, outs[0][0].abs().max().item())
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= tol * scale, cls.__name__
+        for ga, gb in zip(outs[0][1], outs[1][1]):
+            assert (ga - gb).abs().max().item() <= tol * max(1.0, ga.abs().max().item()), cls.__name__

@@ -33,20 +33,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(device, mask_decoder=False):
+def _build(device, mask_decoder=False, model="2d"):
     import bench_train
-    from boxer_amd import BoxAttention, InstanceAttention
     torch.manual_seed(0)
-    model = bench_train.SyntheticBoxeR2D(BoxAttention, LEVELS, d_model=32, n_head=4, d_ffn=64,
-                                         n_enc=2, n_dec=2, n_query=10, n_class=7,
-                                         mask_cls=InstanceAttention if mask_decoder else None
-                                         ).to(device)
-    for m in model.modules():
-        if isinstance(m, (BoxAttention, InstanceAttention)):
-            with torch.no_grad():
-                m.linear_box_weight.normal_(0, 0.05)
-                m.linear_attn_weight.normal_(0, 0.05)
-    return bench_train, model
+    net = bench_train.SyntheticBoxeR(LEVELS, model, d_model=32, n_head=8 if model == "3d" else 4,
+                                     d_ffn=64, n_enc=2, n_dec=2, n_query=10, n_class=7,
+                                     use_mask=mask_decoder).to(device)
+    for m in net.attention_modules():
+        with torch.no_grad():
+            m.linear_box_weight.normal_(0, 0.05)
+            m.linear_attn_weight.normal_(0, 0.05)
+    return bench_train, net
 
 
 def _worker(rank, world, port, out):
@@ -90,23 +87,22 @@ def test_ddp_training_step_world2(tmp_path):
 
 
 def test_encoder_reference_windows():
-    import bench_train
-    ref = bench_train.SyntheticBoxeR2D._pixel_windows([(2, 4)])
+    from boxer_amd import layers
+    ref = layers.encoder_ref_windows_2d([(2, 4)], 1)[0]
     assert ref.shape == (8, 4)
-    assert torch.allclose(ref[0], torch.tensor([0.125, 0.25, 1.0, 2.0]))     # cx, cy, 4/W, 4/H
-    assert torch.allclose(ref[-1, :2], torch.tensor([0.875, 0.75]))
+    assert torch.allclose(ref[0], torch.tensor([0.125, 0.25, 1.0, 2.0]), atol=1e-5)   # cx, cy, 4/W, 4/H
+    assert torch.allclose(ref[-1, :2], torch.tensor([0.875, 0.75]), atol=1e-5)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native_bf16,fused,mask_decoder",
-                         [(False, False, False), (True, True, False), (False, True, True),
-                          (True, False, True)])
-def test_training_step_on_gpu(native_bf16, fused, mask_decoder):
-    from boxer_amd import BoxAttention, InstanceAttention
-    bench_train, model = _build("cuda", mask_decoder)
-    for m in model.modules():
-        if isinstance(m, (BoxAttention, InstanceAttention)):
-            m.native_bf16, m.fused_grid = native_bf16, fused
+@pytest.mark.parametrize("native_bf16,fused,mask_decoder,kind",
+                         [(False, False, False, "2d"), (True, True, False, "2d"),
+                          (False, True, True, "2d"), (True, False, True, "2d"),
+                          (False, False, False, "3d"), (True, True, False, "3d")])
+def test_training_step_on_gpu(native_bf16, fused, mask_decoder, kind):
+    bench_train, model = _build("cuda", mask_decoder, kind)
+    for m in model.attention_modules():
+        m.native_bf16, m.fused_grid = native_bf16, fused
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
     g = torch.Generator().manual_seed(1)
     s = sum(h * w for h, w in LEVELS)
