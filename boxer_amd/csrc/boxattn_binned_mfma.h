@@ -34,6 +34,14 @@
 // 141 instead of 54 us on uniformly random locations).
 // Measured at BoxeR-R50 COCO shapes (C2, bf16): 82 us (VALU kernel) -> 50 us; of the 50: row
 // gathers + staging 17, weight scatter 8, MFMA 3.4 (BOXATTN_TUNE_MFMA_ABLATE).
+//
+// float32 storage (ST = float): the upstream rows are split into two bf16 terms as well,
+// g = g_hi + g_lo (|g - g_hi - g_lo| <= 2^-16 |g|), staged one after the other through the same
+// G^T tile; three products per K-step (g_hi a_hi, g_hi a_lo, g_lo a_hi; g_lo a_lo ~ 2^-25 is
+// dropped).  Every term is accurate to ~2e-5 relative -- inside the operator's 1e-4 float32
+// tolerance, not float32-exact like the VALU kernel.  Rows are fetched one round ahead (two would
+// need 64 more registers).  Measured at C2: accumulate 103 -> 98 us, but the wide records cost
+// 12 us more in the fill pass, so this flavour is opt-in (boxattn_set_variant(11)).
 #pragma once
 #include "boxattn_binned.h"
 
@@ -61,17 +69,20 @@ template <int D> __device__ __forceinline__ unsigned pair_exchange(unsigned x)
     }
 }
 
-template <int C>
+template <typename ST, int C>
 __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
-    const bf16_t *__restrict__ grad_out, BinPlan plan, int S, int H, int Lq,
+    const ST *__restrict__ grad_out, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
-    const int *__restrict__ records, bf16_t *__restrict__ grad_value,
+    const int *__restrict__ records, ST *__restrict__ grad_value,
     float *__restrict__ partials)
 {
+    constexpr bool F32 = sizeof(ST) == 4;
+    static_assert(!F32 || C == 32, "float32 rows: 8 lanes per row");
     constexpr int BW = 8, PB = 32, R = 64;
     constexpr int CP = C < 32 ? 32 : C;            // operand rows: channels padded to the MFMA's 32
     constexpr int NCB = CP / 32;                   // 32-channel blocks
-    constexpr int ROWB = C * 2;                    // bytes of one upstream-gradient row
+    constexpr int ROWB = C * (int)sizeof(ST);      // bytes of one upstream-gradient row
+    constexpr int CPL = 16 / (int)sizeof(ST);      // channels per lane and fetch (8 bf16 / 4 fp32)
     constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each
     constexpr int RPP = 64 / LPR;                  // rows fetched per pass
     constexpr int NPASS = R / RPP;
@@ -125,7 +136,9 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             // (a non-temporal load here, to keep the stream out of the rows' way in L2: 50.7 -> 52.7 us)
             return rr + lane < item.z ? rec[rr + lane] : make_int4(-1, 0, 0, 0);   // id -1: idle lane
         };
-        u32x4 grow[NPASS], grow2[NPASS];          // rows of round r + 1 / r + 2, in flight
+        // bf16: rows of round r + 1 / r + 2 in flight; float32: `grow2` holds the CURRENT round's rows
+        // (needed again for the lo term) and `grow` those of round r + 1
+        u32x4 grow[NPASS], grow2[NPASS];
         auto fetch_rows = [&](const int4 &r, u32x4 (&grow)[NPASS]) {
             if (BOXATTN_TUNE_MFMA_ABLATE & 2) return;
             // (idle lanes, id -1, fetch row 0; it is zeroed when staged)
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
                 int rj = __shfl(row, j, 64);
                 if (BOXATTN_TUNE_MFMA_ABLATE & 32) rj = (rj & 63) + (int)((size_t)b * Lq * H);   // 64 hot rows
-                grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * 8);
+                grow[ps] = *reinterpret_cast<const u32x4 *>(grad_out + (size_t)rj * C + piece * CPL);
             }
         };
         // G^T[c][j] = row j, channel c.  Transposing 16-bit elements one ds_write_b16 at a time
@@ -144,12 +157,12 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         // record's lane for the piece's even channels, the odd one's for the odd channels.
         // n_live: records of the round being staged; the rows of idle lanes are staged as ZEROS (in a
         // dense product 0 * Inf = NaN: a fetched row with a non-finite element would poison the block)
-        auto stage_rows = [&](int n_live) {
+        auto stage_rows = [&](const u32x4 (&rows)[NPASS], int n_live, bool lo_term) {
             if (BOXATTN_TUNE_MFMA_ABLATE & 3) return;
             if (BOXATTN_TUNE_MFMA_ABLATE & 16) {    // rows gathered and waited for, not staged
                 unsigned x = 0;
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) x ^= grow[ps][0] ^ grow[ps][1] ^ grow[ps][2] ^ grow[ps][3];
+                for (int ps = 0; ps < NPASS; ++ps) x ^= rows[ps][0] ^ rows[ps][1] ^ rows[ps][2] ^ rows[ps][3];
                 if (x == 0x12345678u) gt[lane] = (unsigned short)x;
                 return;
             }
@@ -159,10 +172,24 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int j = ps * RPP + lane / LPR, piece = lane % LPR;
                 unsigned int *dst =
-                    reinterpret_cast<unsigned int *>(&gt[(piece * 8 + odd) * GS + (j & ~1)]);
+                    reinterpret_cast<unsigned int *>(&gt[(piece * CPL + odd) * GS + (j & ~1)]);
+                unsigned w[CPL / 2];               // the lane's channels as packed bf16 pairs
+                if constexpr (F32) {
+                    const float f0 = __uint_as_float(rows[ps][0]), f1 = __uint_as_float(rows[ps][1]);
+                    const float f2 = __uint_as_float(rows[ps][2]), f3 = __uint_as_float(rows[ps][3]);
+                    w[0] = pack_bf16x2(f0, f1);
+                    w[1] = pack_bf16x2(f2, f3);
+                    if (lo_term) {                 // g - g_hi, exact in float32
+                        w[0] = pack_bf16x2(f0 - __uint_as_float(w[0] << 16), f1 - __uint_as_float(w[0] & 0xffff0000u));
+                        w[1] = pack_bf16x2(f2 - __uint_as_float(w[1] << 16), f3 - __uint_as_float(w[1] & 0xffff0000u));
+                    }
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned own = j < n_live ? grow[ps][i] : 0u;
+                    for (int i = 0; i < 4; ++i) w[i] = rows[ps][i];
+                }
+#pragma unroll
+                for (int i = 0; i < CPL / 2; ++i) {
+                    const unsigned own = j < n_live ? w[i] : 0u;
                     const unsigned oth = pair_exchange<LPR>(own);       // lane ^ LPR: record j ^ 1
                     dst[i * GS] = __builtin_amdgcn_perm(oth, own, sel);   // rows 2 i + odd, GS ushorts apart
                 }
@@ -171,15 +198,20 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         // rows are gathered TWO rounds ahead (a wave with one round of rows in flight spent most
         // of its time waiting for them), records three
         int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
-        fetch_rows(rec_c, grow);
-        stage_rows(min(R, item.z - item.y));
+        if constexpr (F32) {
+            fetch_rows(rec_c, grow2);
+            stage_rows(grow2, min(R, item.z - item.y), false);
+        } else {
+            fetch_rows(rec_c, grow);
+            stage_rows(grow, min(R, item.z - item.y), false);
+        }
         if (item.y + R < item.z) fetch_rows(rec_n, grow);
         for (int rr = item.y; rr < item.z; rr += R) {
             const int n = min(R, item.z - rr);
             const bool more = rr + R < item.z;     // wave-uniform
             int4 rec_n3 = make_int4(-1, 0, 0, 0);
             if (rr + 2 * R < item.z) {
-                fetch_rows(rec_n2, grow2);
+                if constexpr (!F32) fetch_rows(rec_n2, grow2);
                 rec_n3 = fetch_rec(rr + 3 * R);
             }
             const float2 xy_c = make_float2(__int_as_float(rec_c.y), __int_as_float(rec_c.z));
@@ -245,14 +277,40 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
                         acc[cb][1] += __builtin_bit_cast(u32x4, p_lo)[2];
             }
             wave_lds_sync();
+            if constexpr (F32) {
+                // ---- third product: the lo term of the rows times the hi term of the weights
+                stage_rows(grow2, n, true);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (slot[k] >= 0) at[slot[k]] = whi[k];
+                wave_lds_sync();
+#pragma unroll
+                for (int t = 0; t < R / 16; ++t) {
+                    const int k0 = 16 * t + 8 * kb;
+                    const mfma_bf16x8 p_hi = __builtin_bit_cast(
+                        mfma_bf16x8, *reinterpret_cast<const u32x4 *>(&at[col * AS + k0]));
+                    const u32x2 *gp = reinterpret_cast<const u32x2 *>(&gt[col * GS + k0]);
+                    const u32x2 g0 = gp[0], g1 = gp[1];
+                    const mfma_bf16x8 g_lo = __builtin_bit_cast(mfma_bf16x8, u32x4{g0.x, g0.y, g1.x, g1.y});
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g_lo, p_hi, acc[0], 0, 0, 0);
+                }
+                wave_lds_sync();
+            }
             // ---- clear this round's weights, stage the next round's rows (they have arrived)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (slot[k] >= 0 && !(BOXATTN_TUNE_MFMA_ABLATE & 8)) at[slot[k]] = 0;
             if (more) {
-                stage_rows(min(R, item.z - rr - R));
+                if constexpr (F32) {
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) grow[ps] = grow2[ps];
+                    for (int ps = 0; ps < NPASS; ++ps) grow2[ps] = grow[ps];
+                    stage_rows(grow2, min(R, item.z - rr - R), false);
+                    if (rr + 2 * R < item.z) fetch_rows(rec_n2, grow);      // round r + 2, one round ahead
+                } else {
+                    stage_rows(grow, min(R, item.z - rr - R), false);
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) grow[ps] = grow2[ps];
+                }
                 rec_c = rec_n; rec_n = rec_n2; rec_n2 = rec_n3;
             }
             wave_lds_sync();
@@ -263,8 +321,15 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
             // pairs, so that each writes two 16-byte pieces (8 channels) of the pixel's row
             const int py = col / BW, px = col % BW;
             const bool live = py < bh && px < bw;
-            bf16_t *dst = grad_value +
-                          (((size_t)b * S + lv.start + (size_t)(oy + py) * lv.W + (ox + px)) * H + h) * C;
+            ST *dst = grad_value +
+                      (((size_t)b * S + lv.start + (size_t)(oy + py) * lv.W + (ox + px)) * H + h) * C;
+            if constexpr (F32) {                  // float32 rows: four 16-byte pieces per lane
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    if (live)
+                        *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) = make_float4(
+                            acc[0][4 * g4], acc[0][4 * g4 + 1], acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]);
+            } else
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 unsigned pk[8];

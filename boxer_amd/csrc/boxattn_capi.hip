@@ -561,19 +561,29 @@ template <typename ST> inline bool side_stream_worth(const Dims &) { return fals
 #ifndef BOXATTN_TUNE_WIDE_F32
 #define BOXATTN_TUNE_WIDE_F32 0    // fp32 box attention (VALU accumulate kernel) from wide records: on uniformly random
 #endif                             // locations accumulate 154 -> 103 us, fill +17; on model-like ones only the +17
-// flavours whose accumulate step runs on the matrix cores (boxattn_binned_mfma.h)
-template <typename ST, bool INST> constexpr bool mfma_accumulate()
+// flavours whose accumulate step runs on the matrix cores (boxattn_binned_mfma.h): box attention
+// in bf16 storage.  The float32 flavour of that kernel (two-term bf16 split of the upstream rows,
+// 32 channels per head) exists and is parity-green, but measured no gain at BoxeR-R50 shapes --
+// accumulate 103 -> 98 us, the wide records it needs +12 us in the fill pass -- so float32
+// storage keeps the float32-exact VALU kernel unless boxattn_set_variant(11) asks for it.
+template <typename ST, bool INST> inline bool mfma_accumulate(const Dims &d)
 {
-    return BOXATTN_TUNE_ACC_MFMA && !INST && std::is_same<ST, bf16_t>::value;
+    if (!BOXATTN_TUNE_ACC_MFMA || INST) return false;
+    if (std::is_same<ST, bf16_t>::value) return true;
+    return std::is_same<ST, float>::value && d.C == 32 && g_variant == 11;
 }
 // flavours whose bin passes write 16-byte records {id, x, y, weight}
-template <typename ST, bool INST> constexpr bool wide_records()
+template <typename ST, bool INST> inline bool wide_records(const Dims &d)
 {
-    return mfma_accumulate<ST, INST>() || (BOXATTN_TUNE_WIDE_F32 && !INST && sizeof(ST) == 4);
+    return mfma_accumulate<ST, INST>(d) || (BOXATTN_TUNE_WIDE_F32 && !INST && sizeof(ST) == 4);
 }
-// the workspace query only knows the storage type: room for wide records whenever a flavour of
-// that type may write them
-constexpr bool wide_workspace(bool is_bf16) { return is_bf16 ? BOXATTN_TUNE_ACC_MFMA != 0 : BOXATTN_TUNE_WIDE_F32 != 0; }
+// the workspace query only knows the storage type and the dimensions: room for wide records
+// whenever a flavour of that type may write them
+inline bool wide_workspace(bool is_bf16, const Dims &d)
+{
+    return is_bf16 ? BOXATTN_TUNE_ACC_MFMA != 0
+                   : (BOXATTN_TUNE_WIDE_F32 != 0 || (BOXATTN_TUNE_ACC_MFMA != 0 && d.C == 32));
+}
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -673,8 +683,21 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
 // Binning passes (count, two scans, fill) of the binned backward into the workspace.  They only
 // read the sampling locations, so the training forward can run them ahead of the backward.
 template <bool WIDE, bool INTERLEAVE>
-inline void launch_binning(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                           const WsLayout &w, char *ws, hipStream_t st)
+inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
+                             const WsLayout &w, char *ws, hipStream_t st);
+// wide: 16-byte records; interleave: queries interleaved over the bin workgroups (VALU accumulate)
+inline void launch_binning(bool wide, bool interleave, const float *loc, const float *w_sp,
+                           const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws,
+                           hipStream_t st)
+{
+    if (wide && interleave) launch_binning_t<true, true>(loc, w_sp, d, plan, w, ws, st);
+    else if (wide) launch_binning_t<true, false>(loc, w_sp, d, plan, w, ws, st);
+    else if (interleave) launch_binning_t<false, true>(loc, w_sp, d, plan, w, ws, st);
+    else launch_binning_t<false, false>(loc, w_sp, d, plan, w, ws, st);
+}
+template <bool WIDE, bool INTERLEAVE>
+inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
+                             const WsLayout &w, char *ws, hipStream_t st)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
@@ -783,7 +806,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // passes and the accumulate kernel.  Fork/join with events, so the caller still sees one
     // in-order stream (also valid under stream capture).
     SideStream side(st, side_stream_worth<ST>(d));
-    if (!plan_ready) launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, ws, st);
+    const bool use_mfma = mfma_accumulate<ST, INST>(d), wide = wide_records<ST, INST>(d);
+    if (!plan_ready) launch_binning(wide, !use_mfma, loc, w_sp, d, plan, w, ws, st);
     launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
                                   grad_sp, grad_lv, side.stream());
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
@@ -809,15 +833,32 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
 #define BOXATTN_TUNE_RPL_F32 1
 #endif
         constexpr int kRpl = INST ? 1 : (sizeof(ST) == 2 ? BOXATTN_TUNE_RPL_BF16 : BOXATTN_TUNE_RPL_F32);
-        if constexpr (mfma_accumulate<ST, INST>())
-            hipLaunchKernelGGL((binned_accumulate_mfma_kernel<4 * G>), dim3(wg_per_slice, ns8),
-                               dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
-                               records, grad_value, partials);
-        else
-            hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl, wide_records<ST, INST>()>),
-                               dim3(wg_per_slice, ns8),
-                               dim3(64), 0, st, grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H,
-                               d.Lq, d.P, offsets, items, n_items, records, grad_value, partials);
+        constexpr bool kMfmaBuilt = !INST && (std::is_same<ST, bf16_t>::value ||
+                                              (std::is_same<ST, float>::value && 4 * G == 32));
+        bool done = false;
+        if constexpr (kMfmaBuilt) {
+            if (use_mfma) {
+                hipLaunchKernelGGL((binned_accumulate_mfma_kernel<ST, 4 * G>), dim3(wg_per_slice, ns8),
+                                   dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
+                                   records, grad_value, partials);
+                done = true;
+            }
+        }
+        if (!done) {
+            if constexpr (!INST && sizeof(ST) == 4 && BOXATTN_TUNE_WIDE_F32) {
+                hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl, true>),
+                                   dim3(wg_per_slice, ns8), dim3(64), 0, st, grad_out, grad_mask, loc,
+                                   w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P, offsets, items, n_items,
+                                   records, grad_value, partials);
+            } else if constexpr (!std::is_same<ST, bf16_t>::value || INST) {
+                hipLaunchKernelGGL((binned_accumulate_kernel<ST, 4 * G, INST, kRpl, false>),
+                                   dim3(wg_per_slice, ns8), dim3(64), 0, st, grad_out, grad_mask, loc,
+                                   w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P, offsets, items, n_items,
+                                   records, grad_value, partials);
+            } else {
+                return (int)hipErrorInvalidValue;    // bf16 box attention always has the MFMA kernel
+            }
+        }
     }
     {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
@@ -983,7 +1024,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     const bool plan_ready = plan_kind == 1;
     WsLayout w{};
     if (binned) {
-        w = ws_layout(d, plan, wide_workspace(kBf16));
+        w = ws_layout(d, plan, wide_workspace(kBf16, d));
         binned = workspace_bytes >= w.total;
     }
     if (!binned) {
@@ -1039,7 +1080,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
               fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out, out);
     WsLayout w{};
     if (ok) {
-        w = ws_layout(d, plan, wide_workspace(std::is_same<ST, bf16_t>::value));
+        w = ws_layout(d, plan, wide_workspace(std::is_same<ST, bf16_t>::value, d));
         ok = workspace_bytes >= w.total;
     }
     if (!ok)
@@ -1059,7 +1100,8 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         }
     }
     SideStream side(st, side_stream_worth<ST>(d));
-    launch_binning<wide_records<ST, INST>(), !mfma_accumulate<ST, INST>()>(loc, w_sp, d, plan, w, (char *)workspace, side.stream());
+    launch_binning(wide_records<ST, INST>(d), !mfma_accumulate<ST, INST>(d), loc, w_sp, d, plan, w,
+                   (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
                                         shapes_host, lsi_host);
     side.join();
@@ -1125,7 +1167,7 @@ size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int 
     const size_t fallback = is_bf16 ? align_up(d.n_value() * sizeof(float)) : 0;
     BinPlan plan;
     if (!make_plan(d, shapes_host, lsi_host, plan)) return fallback;
-    size_t need = std::max(fallback, ws_layout(d, plan, wide_workspace(is_bf16 != 0)).total);
+    size_t need = std::max(fallback, ws_layout(d, plan, wide_workspace(is_bf16 != 0, d)).total);
     QgPlan qp;
     if (is_bf16 && make_qg_plan(d, shapes_host, lsi_host, qp))
         need = std::max(need, qg_layout(d, qp).total);

@@ -248,7 +248,10 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
  *       binning next to the training forward).  0 behaves like 4: measured faster for both
  *       storage types.
  *   7 = like 0 without the query-grid forward kernel (row gathers also in the encoder case),
- *   8 = like 0 without the query-grid backward (the binned backward also in the encoder case).
+ *   8 = like 0 without the query-grid backward (the binned backward also in the encoder case),
+ *  11 = like 0 but float32 box attention (32 channels per head) accumulates grad_value on the
+ *       matrix cores (two-term bf16 split of the upstream rows, ~2e-5 relative per term) instead
+ *       of the float32-exact VALU kernel (measured: no gain).
  * Returns the previous value.
  */
 int boxattn_set_variant(int variant);

@@ -19,7 +19,7 @@ from oracle import boxattn_oracle as oc
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 1e-2}
-VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3, "split": 5}
+VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3, "split": 5, "binned_mfma32": 11}
 
 
 def dev(a, dtype=None):
@@ -224,7 +224,7 @@ FAST_CFGS = [SEEDED[0], SEEDED[1], SEEDED[2], SEEDED[3],
              ([(16, 24)], 1, 8, 32, 3000, 4)]                              # chunked heavy bins
 
 
-@pytest.mark.parametrize("variant", ["atomic", "binned"])
+@pytest.mark.parametrize("variant", ["atomic", "binned", "binned_mfma32"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", FAST_CFGS, ids=[str(i) for i in range(len(FAST_CFGS))])
 def test_box_backward_algorithms(cfg, dtype, variant):
@@ -768,7 +768,19 @@ def test_training_forward_plan(dtype):
     close(gv3, want3[0], dtype, "grad_value (plan with stale weights ignored)")
 
 
-def test_functions_use_the_plan_and_match():
+@pytest.mark.parametrize("plan_in_forward", [False, True])
+def test_functions_use_the_plan_and_match(plan_in_forward):
+    """The autograd Functions with and without the forward preparing the backward's plan
+    (functions.PLAN_IN_FORWARD; off by default: the workspace is then transient)."""
+    from boxer_amd import BoxAttnFunction, InstanceAttnFunction, functions
+    old = functions.set_plan_in_forward(plan_in_forward)
+    try:
+        _functions_match()
+    finally:
+        functions.set_plan_in_forward(old)
+
+
+def _functions_match():
     from boxer_amd import BoxAttnFunction, InstanceAttnFunction
     g = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 200, 4, seed=43)
     shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
