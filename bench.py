@@ -492,6 +492,8 @@ def main():
                     help="capture the step in a HIP graph and time replays (not the headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the parity gate")
+    ap.add_argument("--preheat-s", type=float, default=PREHEAT_SECONDS,
+                    help="untimed pre-heat before the protocol, seconds (profiling runs pass 0)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
     args = ap.parse_args()
     if args.batch is None:
@@ -538,7 +540,7 @@ def main():
     # the W warm-up + K timed steps of the protocol, so that the number is the steady-state one.
     preheat, t0 = 0, time.perf_counter()
     while preheat < max(0, PREHEAT_STEPS - args.warmup) or \
-            time.perf_counter() - t0 < PREHEAT_SECONDS:
+            time.perf_counter() - t0 < args.preheat_s:
         step()
         preheat += 1
         if preheat % 64 == 0:

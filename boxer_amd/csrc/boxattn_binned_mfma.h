@@ -187,9 +187,13 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) w[i] = rows[ps][i];
                 }
+                if (n_live < R) {                  // wave-uniform: only an item's last round has idle lanes
+#pragma unroll
+                    for (int i = 0; i < CPL / 2; ++i) w[i] = j < n_live ? w[i] : 0u;
+                }
 #pragma unroll
                 for (int i = 0; i < CPL / 2; ++i) {
-                    const unsigned own = j < n_live ? w[i] : 0u;
+                    const unsigned own = w[i];
                     const unsigned oth = pair_exchange<LPR>(own);       // lane ^ LPR: record j ^ 1
                     dst[i * GS] = __builtin_amdgcn_perm(oth, own, sel);   // rows 2 i + odd, GS ushorts apart
                 }
