@@ -13,7 +13,7 @@ features (N(0,1)), positional embeddings, matcher / criterion (a dummy regressio
 class and box heads).  One process per GPU; gradients are all-reduced by DistributedDataParallel
 (RCCL with backend "nccl", gloo in the CPU test) -- the operator itself never communicates.
 
-  python bench_train.py [--steps 10 --warmup 3 --dtype bf16|fp32 --fused-grid --fused-pointwise
+  python bench_train.py [--steps 30 --warmup 10 --dtype bf16|fp32 --fused-grid --fused-pointwise
                          --model 2d|3d --mask-decoder]
   python bench_train.py --gpus N          (starts its own N ranks; or under torch.distributed.run)
 prints ONE JSON line on rank 0: ms per step (MAX over ranks), images/s, operator share.
@@ -127,12 +127,13 @@ def train_step(model, opt, batch, autocast_dtype=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"],
                     help="bf16: autocast for the dense layers + the operator's native bf16 mode")
-    ap.add_argument("--fused-grid", action="store_true")
+    ap.add_argument("--fused-grid", nargs="?", const=1, default=0, type=int,
+                    help="1: grid construction in one kernel each way; 2: inside the sampling kernels")
     ap.add_argument("--fused-pointwise", action="store_true",
                     help="softmax and value mask + cast as single HIP passes (module.fused_pointwise)")
     ap.add_argument("--mask-decoder", action="store_true",

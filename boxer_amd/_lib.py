@@ -41,6 +41,15 @@ _HL_SIGNATURES = {
     # forward args + shapes_host, lsi_host, stream
     "boxattn_fwd_hl": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp],
 }
+_GRIDATTN_SIGNATURES = {
+    # value, shapes, lsi, ref, ref_dim, ref_per_head, offsets, V, angle_mode, kidx, vr, attn, dims, out, grid, stream
+    "boxattn_fwd_grid": [_vp] * 4 + [_i, _i, _vp, _i, _i, _vp, _vp, _vp] + _DIMS + [_vp, _vp, _vp],
+    # value, shapes, lsi, grid, attn, grad_out, ref, ref_dim, ref_per_head, offsets, V, angle_mode, kidx, vr,
+    # dims, grad_value, grad_offsets, grad_ref_rows, grad_attn, shapes_host, lsi_host, ws, ws_bytes, stream
+    "boxattn_bwd_ws_grid": [_vp] * 7 + [_i, _i, _vp, _i, _i, _vp, _vp] + _DIMS + [_vp] * 4 +
+                           [_vp, _vp, _vp, ctypes.c_size_t, _vp],
+}
+NOT_ELIGIBLE = -2
 _ll = ctypes.c_longlong
 _POINTWISE_SIGNATURES = {
     "boxattn_softmax_fwd_f32": [_vp, _ll, _i, _vp, _vp],
@@ -58,6 +67,8 @@ _GRID_SIGNATURES = {
 }
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "boxattn_set_option",
            "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16", *sorted(_POINTWISE_SIGNATURES),
+           "boxattn_fwd_grid_f32", "boxattn_fwd_grid_bf16", "boxattn_bwd_ws_grid_f32",
+           "boxattn_bwd_ws_grid_bf16",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
@@ -126,6 +137,11 @@ def load():
             fn.argtypes = args
             fn.restype = _i
     for stem, args in _HL_SIGNATURES.items():
+        for suf in ("f32", "bf16"):
+            fn = getattr(lib, "%s_%s" % (stem, suf))
+            fn.argtypes = args
+            fn.restype = _i
+    for stem, args in _GRIDATTN_SIGNATURES.items():
         for suf in ("f32", "bf16"):
             fn = getattr(lib, "%s_%s" % (stem, suf))
             fn.argtypes = args

@@ -159,6 +159,7 @@ inline int finish()
 {
     return (int)hipGetLastError();
 }
+constexpr int kNotEligible = BOXATTN_NOT_ELIGIBLE;   // "use the unfused entry points" (no launch was made)
 
 // ---- optional kernel timing (boxattn_profile_begin/_end) -------------------------------
 struct EventPair { hipEvent_t a, b; };
@@ -399,6 +400,33 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     hipLaunchKernelGGL((fwd_generic_kernel<ST, INST>), dim3(blocks), dim3(256), 0, st, value,
                        shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.C, d.L, d.Lq, d.P, out, mask,
                        n);
+    return finish();
+}
+
+// Forward from boxes (GRID flavour of fwd2_kernel): also writes the sampling grid.
+template <typename ST>
+int launch_fwd_grid(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *attn,
+                    const Dims &d, ST *out, const GridSrc &gs, hipStream_t st)
+{
+    if (!d.valid()) return (int)hipErrorInvalidValue;
+    if (d.empty() || d.n_value() == 0) return kNotEligible;
+    if (!value || !shapes || !lsi || !attn || !out || !gs.ref || !gs.offsets || !gs.kidx || !gs.grid_out)
+        return (int)hipErrorInvalidValue;
+    GatherIdx ix{};
+    const size_t vbytes = d.n_value() * sizeof(ST);
+    if (!fast_ok<ST>(d, value, gs.grid_out, out, out, out) || g_variant == 2 || vbytes >= kOobOffset ||
+        !gather_idx(d, ix, sizeof(ST)))
+        return kNotEligible;
+    const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(out, 16));
+    const int blocks = gather_blocks(d, ix, kWave / cfg.G);
+    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+#define BOXATTN_FWD2G(GG, VV)                                                                      \
+    hipLaunchKernelGGL((fwd2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV, true>),   \
+                       dim3(blocks, 1), dim3(256), 0, st, value, shapes, lsi, (const float *)nullptr, \
+                       attn, (const float *)nullptr, d.S, d.H, d.L, d.Lq, d.P, out, (ST *)nullptr, ix, \
+                       (unsigned)vbytes, gs);
+    BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2G);
+#undef BOXATTN_FWD2G
     return finish();
 }
 
@@ -737,12 +765,27 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
 #undef BOXATTN_BIN
 }
 
+// Can the point-gradient kernel reduce the location gradients to box gradients itself (GRID
+// flavour of pointgrad2_kernel: buffered epilogue, one launch row)?
+template <typename ST>
+bool pointgrad_grid_ok(const Dims &d, const void *value, const void *grad_out, const void *grad_sp)
+{
+    GatherIdx ix{};
+    if (d.P != 4 || (d.L * d.P != 16 && d.L * d.P != 8)) return false;
+    if (d.n_value() * sizeof(ST) >= kOobOffset || !gather_idx(d, ix, sizeof(ST))) return false;
+    const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16));
+    if (cfg.G != 4 && cfg.G != 8) return false;
+    const int blocks = gather_blocks(d, ix, kWave / cfg.G);
+    return point_split(blocks, (d.L * d.P + cfg.G - 1) / cfg.G) == 1 && aligned(grad_sp, 16);
+}
+
 // Point gradients (grad_loc / grad_weight): query-major gathers, independent of how grad_value
 // is accumulated.
 template <typename ST, int G, bool INST>
 void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
-                      const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st)
+                      const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st,
+                      const GridSrc *gs = nullptr)
 {
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
     const size_t n_qh = d.n_qh();
@@ -773,6 +816,20 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
 #undef BOXATTN_PG2W
         } else {
             const int split = point_split(blocks, tiles);
+            if constexpr (!INST) {
+                if (gs) {        // boxes in, box gradients out (pointgrad_grid_ok() was checked)
+#define BOXATTN_PG2G(GG, VV)                                                                        \
+    if constexpr (GG == 4 || GG == 8)                                                               \
+        hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV,   \
+                                              false, true>),                                        \
+                           dim3(blocks, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
+                           grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp,        \
+                           grad_lv, ix, (unsigned)vbytes, *gs);
+                    BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2G);
+#undef BOXATTN_PG2G
+                    return;
+                }
+            }
 #define BOXATTN_PG2(GG, VV)                                                                   \
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
                    dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
@@ -794,7 +851,8 @@ template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
-               float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st)
+               float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st,
+               const GridSrc *gs = nullptr)
 {
     const int ns = d.B * d.H;
     int *n_items = (int *)(ws + w.n_items);
@@ -809,7 +867,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     const bool use_mfma = mfma_accumulate<ST, INST>(d), wide = wide_records<ST, INST>(d);
     if (!plan_ready) launch_binning(wide, !use_mfma, loc, w_sp, d, plan, w, ws, st);
     launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
-                                  grad_sp, grad_lv, side.stream());
+                                  grad_sp, grad_lv, side.stream(), gs);
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
     // real count lives on the device, surplus workgroups exit at once); the hardware dispatcher
     // hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
@@ -991,7 +1049,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                  size_t workspace_bytes, int plan_kind, hipStream_t st)
+                  size_t workspace_bytes, int plan_kind, hipStream_t st, const GridSrc *gs = nullptr)
 {
     // plan_kind: what the training forward left in the workspace -- 0 nothing, 1 the binning
     // plan, 2 the query-grid tile boxes (the value *_fwd_train_* returned in *plan_built)
@@ -1004,6 +1062,8 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   fast_ok<ST>(d, value, loc, grad_out,
                               INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
                   aligned(workspace, 256) && aligned(grad_value, 16);
+    if (gs && (!binned || INST || !pointgrad_grid_ok<ST>(d, value, grad_out, grad_sp)))
+        return kNotEligible;                 // the caller falls back to the grid tensor's own kernels
     if constexpr (kBf16 && !INST) {      // encoder case: no global binning (boxattn_qgrid.h)
         QgPlan qp;
         if (binned && plan_kind != 1 && aligned(grad_out, 16) && aligned(loc, 16) &&
@@ -1014,7 +1074,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                     !grad_value || !value)
                     return (int)hipErrorInvalidValue;
                 launch_pointgrad<ST, 8, false>(value, shapes, lsi, loc, w_sp, w_lv, grad_out,
-                                               grad_mask, d, grad_loc, grad_sp, grad_lv, st);
+                                               grad_mask, d, grad_loc, grad_sp, grad_lv, st, gs);
                 return run_qgrid(grad_out, loc, w_sp, d, qp, qw, (char *)workspace, grad_value,
                                  plan_kind == 2, st);
             }
@@ -1051,7 +1111,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
-                                      plan_ready, st);                                          \
+                                      plan_ready, st, gs);                                      \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -1435,9 +1495,100 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
 }
 
 
+
+// ---- box attention straight from boxes (second step) ----------------------
+static int grid_src(const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                    int angle_mode, const float *kernel_idx, const float *valid_ratios, int B, int Lq,
+                    int H, int L, int P, GridSrc &gs)
+{
+    GridDims gd{};
+    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, gd);
+    if (ok != 1 || !ref || !offsets || !kernel_idx) return ok == 2 ? BOXATTN_NOT_ELIGIBLE : (int)hipErrorInvalidValue;
+    gs = GridSrc{ref, offsets, kernel_idx, valid_ratios, gd, nullptr, nullptr, nullptr};
+    return 0;
+}
+
+int boxattn_fwd_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                         int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                         const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
+                         float *out, float *grid, void *stream)
+{
+    GridSrc gs;
+    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
+                          B, Lq, H, L, P, gs))
+        return rc;
+    gs.grid_out = grid;
+    return launch_fwd_grid<float>(value, shapes, lsi, attn, DIMS, out, gs, ST_);
+}
+int boxattn_fwd_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                          int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                          const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
+                          uint16_t *out, float *grid, void *stream)
+{
+    GridSrc gs;
+    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
+                          B, Lq, H, L, P, gs))
+        return rc;
+    gs.grid_out = grid;
+    return launch_fwd_grid<bf16_t>(value, shapes, lsi, attn, DIMS, out, gs, ST_);
+}
+int boxattn_bwd_ws_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *grid, const float *attn, const float *grad_out,
+                            const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                            int angle_mode, const float *kernel_idx, const float *valid_ratios, int B,
+                            int S, int H, int C, int L, int Lq, int P, float *grad_value,
+                            float *grad_offsets, float *grad_ref_rows, float *grad_attn,
+                            const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                            size_t workspace_bytes, void *stream)
+{
+    GridSrc gs;
+    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
+                          B, Lq, H, L, P, gs))
+        return rc;
+    if (!grad_offsets) return (int)hipErrorInvalidValue;
+    gs.grad_offsets = grad_offsets;
+    gs.grad_ref_rows = grad_ref_rows;
+    return launch_bwd_ws<float, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
+                                       DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
+                                       grad_attn, nullptr, shapes_host, lsi_host, workspace,
+                                       workspace_bytes, 0, ST_, &gs);
+}
+int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                             const float *grid, const float *attn, const uint16_t *grad_out,
+                             const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                             int V, int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                             int B, int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                             float *grad_offsets, float *grad_ref_rows, float *grad_attn,
+                             const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                             size_t workspace_bytes, void *stream)
+{
+    GridSrc gs;
+    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
+                          B, Lq, H, L, P, gs))
+        return rc;
+    if (!grad_offsets) return (int)hipErrorInvalidValue;
+    gs.grad_offsets = grad_offsets;
+    gs.grad_ref_rows = grad_ref_rows;
+    return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
+                                        DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
+                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
+                                        workspace_bytes, 0, ST_, &gs);
+}
+
 }  // extern "C"
 
 // ---- pointwise work around the operator ---------------------------------
+// lanes per row of the vector kernels (rows of 4, 8, 16, 32 or 64 values, 16-byte aligned
+// tensors), 0: the one-thread-per-row kernels
+template <typename T>
+static int softmax_group(int n, const T *typed, const float *f32)
+{
+    if (n % 4 != 0 || (n / 4 & (n / 4 - 1)) != 0 || n > 64) return 0;
+    return aligned(typed, 16) && aligned(f32, 16) ? n / 4 : 0;
+}
+
 template <typename T>
 static int softmax_fwd(const T *logits, long long rows, int n, float *attn, hipStream_t st)
 {
@@ -1445,7 +1596,18 @@ static int softmax_fwd(const T *logits, long long rows, int n, float *attn, hipS
     if (rows == 0) return 0;
     if (!logits || !attn) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((rows + 255) / 256);
-    if (n <= 16)
+    const int g = softmax_group(n, logits, attn);
+    const size_t total = (size_t)rows * n;
+    const unsigned vblocks = (unsigned)((total / 4 + 255) / 256);
+#define BOXATTN_SOFTMAX_VEC(G) \
+    hipLaunchKernelGGL((softmax_vec_fwd_kernel<T, G>), dim3(vblocks), dim3(256), 0, st, logits, total, attn)
+    if (g == 1) BOXATTN_SOFTMAX_VEC(1);
+    else if (g == 2) BOXATTN_SOFTMAX_VEC(2);
+    else if (g == 4) BOXATTN_SOFTMAX_VEC(4);
+    else if (g == 8) BOXATTN_SOFTMAX_VEC(8);
+    else if (g == 16) BOXATTN_SOFTMAX_VEC(16);
+#undef BOXATTN_SOFTMAX_VEC
+    else if (n <= 16)
         hipLaunchKernelGGL((softmax_rows_fwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, logits,
                            (size_t)rows, n, attn);
     else
@@ -1461,7 +1623,19 @@ static int softmax_bwd(const float *attn, const float *grad_attn, long long rows
     if (rows == 0) return 0;
     if (!attn || !grad_attn || !grad_logits) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((rows + 255) / 256);
-    if (n <= 16)
+    const int g = aligned(grad_attn, 16) ? softmax_group(n, grad_logits, attn) : 0;
+    const size_t total = (size_t)rows * n;
+    const unsigned vblocks = (unsigned)((total / 4 + 255) / 256);
+#define BOXATTN_SOFTMAX_VEC(G) \
+    hipLaunchKernelGGL((softmax_vec_bwd_kernel<T, G>), dim3(vblocks), dim3(256), 0, st, attn, \
+                       grad_attn, total, grad_logits)
+    if (g == 1) BOXATTN_SOFTMAX_VEC(1);
+    else if (g == 2) BOXATTN_SOFTMAX_VEC(2);
+    else if (g == 4) BOXATTN_SOFTMAX_VEC(4);
+    else if (g == 8) BOXATTN_SOFTMAX_VEC(8);
+    else if (g == 16) BOXATTN_SOFTMAX_VEC(16);
+#undef BOXATTN_SOFTMAX_VEC
+    else if (n <= 16)
         hipLaunchKernelGGL((softmax_rows_bwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, attn,
                            grad_attn, (size_t)rows, n, grad_logits);
     else

@@ -55,6 +55,76 @@ __device__ __forceinline__ GridBox grid_box(const float *__restrict__ ref,
     return g;
 }
 
+// grid point p of a decoded box (the body of grid_fwd_kernel, shared with the sampling kernels
+// that take boxes instead of a grid: same operations, same order, no FMA contraction)
+__device__ __forceinline__ float2 grid_point(const GridBox &g, const float *__restrict__ kidx,
+                                             int p, bool has_vr, int angle_mode)
+{
+#pragma clang fp contract(off)
+    const float lx = kidx[2 * p] * fmaxf(g.w, 0.f), ly = kidx[2 * p + 1] * fmaxf(g.h, 0.f);
+    float gx, gy;
+    if (angle_mode) {
+        gx = g.cx + (lx * g.cs - ly * g.sn);
+        gy = g.cy + (lx * g.sn + ly * g.cs);
+    } else {
+        gx = g.cx + lx;
+        gy = g.cy + ly;
+    }
+    if (has_vr) {
+        gx = gx * g.vx;
+        gy = gy * g.vy;
+    }
+    return make_float2(gx, gy);
+}
+
+// one point's share of the box gradient (the loop body of grid_bwd_kernel)
+struct GridGrad { float cx, cy, w, h, t; };
+__device__ __forceinline__ void grid_grad_add(GridGrad &a, const GridBox &g, const float *__restrict__ kidx,
+                                              int p, float2 q)
+{
+    const float wr = fmaxf(g.w, 0.f), hr = fmaxf(g.h, 0.f);
+    const float gx = q.x * g.vx, gy = q.y * g.vy;           // d / d (unscaled grid)
+    const float kx = kidx[2 * p], ky = kidx[2 * p + 1];
+    a.cx += gx;
+    a.cy += gy;
+    a.w += kx * (gx * g.cs + gy * g.sn);                     // d / d relu(w)
+    a.h += ky * (gy * g.cs - gx * g.sn);                     // d / d relu(h)
+    const float lx = kx * wr, ly = ky * hr;
+    a.t += gx * (-lx * g.sn - ly * g.cs) + gy * (lx * g.cs - ly * g.sn);
+}
+// ... and the row's results from the summed shares (the tail of grid_bwd_kernel)
+__device__ __forceinline__ void grid_grad_store(GridGrad a, const GridBox &g, const float *__restrict__ o,
+                                                const GridDims &d, float *__restrict__ go,
+                                                float *__restrict__ gr)
+{
+    a.w = g.w > 0.f ? a.w : 0.f;                             // relu'
+    a.h = g.h > 0.f ? a.h : 0.f;
+    go[0] = a.cx * g.rw / 8.f;
+    go[1] = a.cy * g.rh / 8.f;
+    go[2] = a.w * g.rw / 8.f;
+    go[3] = a.h * g.rh / 8.f;
+    const float two_pi = 2.f * 3.14159265358979323846f;
+    if (d.V == 5) go[4] = d.angle_mode == 1 ? a.t * two_pi / 16.f : 0.f;
+    if (gr) {
+        gr[0] = a.cx;
+        gr[1] = a.cy;
+        gr[2] = a.cx * o[0] / 8.f + a.w * (1.f + o[2] / 8.f);
+        gr[3] = a.cy * o[1] / 8.f + a.h * (1.f + o[3] / 8.f);
+        gr[4] = d.angle_mode == 1 ? a.t * two_pi : (d.angle_mode == 2 ? a.t : 0.f);
+    }
+}
+
+// What the sampling kernels need to work from boxes (second step): the
+// forward computes every point's location from its box and also stores the grid (the backward's
+// kernels read it); the point-gradient kernel reduces the location gradients of a (query, head,
+// level) row to grad_offsets / grad_ref_rows itself instead of writing grad_loc.
+struct GridSrc {
+    const float *ref, *offsets, *kidx, *vr;
+    GridDims d;
+    float *grid_out;                  // forward
+    float *grad_offsets, *grad_ref_rows;   // backward (grad_ref_rows may be null)
+};
+
 __global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__ ref,
                                                        const float *__restrict__ offsets,
                                                        const float *__restrict__ kidx,
@@ -67,20 +137,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__
     const size_t n = i / (unsigned)d.P;
     const int p = (int)(i - n * (unsigned)d.P);
     const GridBox g = grid_box(ref, offsets, vr, d, n);
-    const float lx = kidx[2 * p] * fmaxf(g.w, 0.f), ly = kidx[2 * p + 1] * fmaxf(g.h, 0.f);
-    float gx, gy;
-    if (d.angle_mode) {
-        gx = g.cx + (lx * g.cs - ly * g.sn);
-        gy = g.cy + (lx * g.sn + ly * g.cs);
-    } else {
-        gx = g.cx + lx;
-        gy = g.cy + ly;
-    }
-    if (vr) {
-        gx = gx * g.vx;
-        gy = gy * g.vy;
-    }
-    reinterpret_cast<float2 *>(grid)[i] = make_float2(gx, gy);
+    reinterpret_cast<float2 *>(grid)[i] = grid_point(g, kidx, p, vr != nullptr, d.angle_mode);
 }
 
 // grad_offsets (N, V) and, if asked for, the per-row gradient of the reference window
@@ -102,40 +159,13 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
     if (!live) n = n_rows - 1;                                  // keep the quad together
     const GridBox g = grid_box(ref, offsets, vr, d, n);
     const float2 *gg = reinterpret_cast<const float2 *>(grad_grid) + n * (unsigned)d.P;
-    float gcx = 0.f, gcy = 0.f, gw = 0.f, gh = 0.f, gt = 0.f;
-    const float wr = fmaxf(g.w, 0.f), hr = fmaxf(g.h, 0.f);
-    for (int p = j; p < d.P; p += 4) {
-        const float2 q = gg[p];
-        const float gx = q.x * g.vx, gy = q.y * g.vy;           // d / d (unscaled grid)
-        const float kx = kidx[2 * p], ky = kidx[2 * p + 1];
-        gcx += gx;
-        gcy += gy;
-        gw += kx * (gx * g.cs + gy * g.sn);                     // d / d relu(w)
-        gh += ky * (gy * g.cs - gx * g.sn);                     // d / d relu(h)
-        const float lx = kx * wr, ly = ky * hr;
-        gt += gx * (-lx * g.sn - ly * g.cs) + gy * (lx * g.cs - ly * g.sn);
-    }
-    gcx = group_sum<4>(gcx); gcy = group_sum<4>(gcy);
-    gw = group_sum<4>(gw); gh = group_sum<4>(gh); gt = group_sum<4>(gt);
+    GridGrad a{0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = j; p < d.P; p += 4) grid_grad_add(a, g, kidx, p, gg[p]);
+    a.cx = group_sum<4>(a.cx); a.cy = group_sum<4>(a.cy);
+    a.w = group_sum<4>(a.w); a.h = group_sum<4>(a.h); a.t = group_sum<4>(a.t);
     if (!(live && j == 0)) return;
-    gw = g.w > 0.f ? gw : 0.f;                                  // relu'
-    gh = g.h > 0.f ? gh : 0.f;
-    const float *o = offsets + n * (unsigned)d.V;
-    float *go = grad_offsets + n * (unsigned)d.V;
-    go[0] = gcx * g.rw / 8.f;
-    go[1] = gcy * g.rh / 8.f;
-    go[2] = gw * g.rw / 8.f;
-    go[3] = gh * g.rh / 8.f;
-    const float two_pi = 2.f * 3.14159265358979323846f;
-    if (d.V == 5) go[4] = d.angle_mode == 1 ? gt * two_pi / 16.f : 0.f;
-    if (grad_ref_rows) {
-        float *gr = grad_ref_rows + n * 5;
-        gr[0] = gcx;
-        gr[1] = gcy;
-        gr[2] = gcx * o[0] / 8.f + gw * (1.f + o[2] / 8.f);
-        gr[3] = gcy * o[1] / 8.f + gh * (1.f + o[3] / 8.f);
-        gr[4] = d.angle_mode == 1 ? gt * two_pi : (d.angle_mode == 2 ? gt : 0.f);
-    }
+    grid_grad_store(a, g, offsets + n * (unsigned)d.V, d, grad_offsets + n * (unsigned)d.V,
+                    grad_ref_rows ? grad_ref_rows + n * 5 : nullptr);
 }
 
 
@@ -148,8 +178,10 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
 //     written in the logits' type;
 //   * value rows of padded pixels (v_mask) zeroed and cast to bfloat16 in the same pass
 //     (`value.masked_fill(v_mask[..., None], 0)` followed by the op's bf16 conversion).
-// One thread per row; N = L*P is small (16 for BoxeR's 2x2 grids on 4 levels), a row is one or
-// two cache lines, neighbouring threads read neighbouring rows.
+// Rows whose length is 4 * 2^k (k <= 4; BoxeR: 16 = 4 levels x 2x2 points): 2^k lanes per row,
+// four consecutive values per lane, so a wave reads and writes whole contiguous runs
+// (element index = 4 * thread) and the row max / sum are cross-lane butterflies.  Any other
+// length <= 64: one thread per row (strided accesses; the rare shapes).
 // ---------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float pw_ld(const T *p);
 template <> __device__ __forceinline__ float pw_ld<float>(const float *p) { return *p; }
@@ -209,6 +241,52 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__re
         if (i < n) pw_st<T>(dst + i, av[i] * (gv[i] - dot));
 }
 
+template <int G> __device__ __forceinline__ float group_max(float v)
+{
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_add(float v)
+{
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G>         // n = 4 G values per row, G lanes per row
+__global__ __launch_bounds__(256) void softmax_vec_fwd_kernel(const T *__restrict__ logits,
+                                                              size_t total, float *__restrict__ attn)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool live = i < total;             // rows are whole multiples of the group: uniform per row
+    float v[4];
+    VecIO<T, 4>::ld(logits + (live ? i : 0), v);
+    const float m = group_max<G>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __expf(v[k] - m);
+    const float inv = 1.f / group_add<G>((v[0] + v[1]) + (v[2] + v[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= inv;
+    if (live) VecIO<float, 4>::st(attn + i, v);
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void softmax_vec_bwd_kernel(const float *__restrict__ attn,
+                                                              const float *__restrict__ grad_attn,
+                                                              size_t total, T *__restrict__ grad_logits)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool live = i < total;
+    float a[4], g[4];
+    VecIO<float, 4>::ld(attn + (live ? i : 0), a);
+    VecIO<float, 4>::ld(grad_attn + (live ? i : 0), g);
+    const float dot = group_add<G>((a[0] * g[0] + a[1] * g[1]) + (a[2] * g[2] + a[3] * g[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] *= g[k] - dot;
+    if (live) VecIO<T, 4>::st(grad_logits + i, a);
+}
+
 // value (rows, d) of type T -> bfloat16, rows with mask != 0 zeroed; 8 channels per thread
 template <typename T>
 __global__ __launch_bounds__(256) void value_mask_cast_kernel(const T *__restrict__ value,
@@ -221,8 +299,19 @@ __global__ __launch_bounds__(256) void value_mask_cast_kernel(const T *__restric
     const size_t r = i / (unsigned)d;
     const bool dead = mask && mask[r];
     float v[8];
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        VecIO<bf16_t, 8>::ld(value + i, v);
+    } else {
+        float lo[4], hi[4];
+        VecIO<float, 4>::ld(value + i, lo);
+        VecIO<float, 4>::ld(value + i + 4, hi);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = dead ? 0.f : pw_ld<T>(value + i + k);
+        for (int k = 0; k < 4; ++k) { v[k] = lo[k]; v[4 + k] = hi[k]; }
+    }
+    if (dead) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
     VecIO<bf16_t, 8>::st(out + i, v);
 }
 

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
+from .functions import (BoxAttnBF16Function, BoxAttnFromBoxesFunction, BoxAttnFunction, BoxGridFunction,
                         InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
                         ValueMaskCastFunction)
 
@@ -48,7 +48,9 @@ class _BoxAttentionBase(nn.Module):
         self.head_dim = d_model // num_head
         self.kernel_size = kernel_size
         self.native_bf16 = False
-        # opt-in: box -> grid expansion in one HIP kernel each way (BoxGridFunction)
+        # opt-in: True / 1 = box -> grid expansion in one HIP kernel each way (BoxGridFunction);
+        # 2 = the grid is built inside the sampling kernels (BoxAttnFromBoxesFunction): no
+        # separate grid kernels, no grad_loc tensor (BoxAttention / Box3dAttention)
         self.fused_grid = False
         # opt-in: the softmax over the L*P logits and, in the bf16 storage mode, the value
         # mask-fill + bf16 cast as single HIP passes (LogitSoftmaxFunction, ValueMaskCastFunction)
@@ -78,7 +80,8 @@ class _BoxAttentionBase(nn.Module):
         b, s = value.shape[:2]
         value = self.value_proj(value)
         if (self.fused_pointwise and self.native_bf16 and value.is_cuda and
-                value.dtype in (torch.float32, torch.bfloat16) and self.d_model % 8 == 0):
+                value.dtype in (torch.float32, torch.bfloat16) and self.d_model % 8 == 0 and
+                (v_mask is not None or value.dtype != torch.bfloat16)):   # else: nothing to do
             value = ValueMaskCastFunction.apply(value, v_mask)
         elif v_mask is not None:
             value = value.masked_fill(v_mask[..., None], float(0))
@@ -149,12 +152,21 @@ class BoxAttention(_BoxAttentionBase):
         w = self._softmax(w.view(b, l1, self.num_head, -1))
         return w.view(b, l1, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
 
+    def _angle_mode(self):
+        return 0
+
     def forward(self, query, value, v_shape, v_mask, v_start_index, v_valid_ratios, ref_windows):
         value = self._project_value(value, v_mask)
         attn_weights = self._softmax_weights(query)
-        sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
-        output = self._box_function().apply(value, v_shape, v_start_index, sampled_grid,
-                                            attn_weights, self.im2col_step)
+        if self.fused_grid == 2 and self._use_fused_grid(query, v_valid_ratios):
+            offsets = self._box_offsets(query, ref_windows, 5 if self._angle_mode() == 1 else 4)
+            output = BoxAttnFromBoxesFunction.apply(
+                value, v_shape, v_start_index, ref_windows, offsets, self.kernel_indices,
+                v_valid_ratios, self._angle_mode(), attn_weights, self.native_bf16)
+        else:
+            sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
+            output = self._box_function().apply(value, v_shape, v_start_index, sampled_grid,
+                                                attn_weights, self.im2col_step)
         return self.out_proj(output), attn_weights
 
 
@@ -168,6 +180,9 @@ class Box3dAttention(BoxAttention):
         self.with_rotation = with_rotation
         self.num_variable = 5 if with_rotation else 4
         self.num_point = kernel_size ** 2
+
+    def _angle_mode(self):
+        return 1 if self.with_rotation else 2
 
     def _where_to_attend(self, query, v_valid_ratios, ref_windows):
         b, l = ref_windows.shape[:2]

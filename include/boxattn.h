@@ -257,6 +257,50 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
 int boxattn_set_variant(int variant);
 
 /*
+ * ---- box attention straight from boxes (opt-in; SURVEY.md 8(f) N1, second step) -------------
+ * The modules' `_where_to_attend` tail (see boxattn_grid_*) inside the sampling kernels:
+ *   boxattn_fwd_grid_*     the forward computes every sample point from its box (reference window
+ *                          + predicted offsets; arguments as boxattn_grid_fwd_f32) instead of
+ *                          reading a grid, and stores the grid (B,Lq,H,L,P,2) on the way -- the
+ *                          backward's kernels read it;
+ *   boxattn_bwd_ws_grid_*  the backward of boxattn_bwd_ws_* with the point-gradient kernel reducing
+ *                          the location gradients of every (query, head, level) row to grad_offsets
+ *                          (B,Lq,H,L,V) and, if grad_ref_rows (B,Lq,H,L,5) is not NULL, the row's
+ *                          gradient of the reference window, as boxattn_grid_bwd_f32 would: no
+ *                          grad_loc tensor is written or read.
+ * Both return BOXATTN_NOT_ELIGIBLE -- nothing was launched -- for shapes their kernels are not
+ * built for (the backward needs P = 4, L*P = 8 or 16, a shape the binned algorithm accepts, and
+ * enough queries for one launch row); the caller then uses boxattn_grid_* + the plain entries.
+ */
+#define BOXATTN_NOT_ELIGIBLE (-2)
+int boxattn_fwd_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                         int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                         const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
+                         float *out, float *grid, void *stream);
+int boxattn_fwd_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                          int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                          const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
+                          uint16_t *out, float *grid, void *stream);
+int boxattn_bwd_ws_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *grid, const float *attn, const float *grad_out,
+                            const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
+                            int angle_mode, const float *kernel_idx, const float *valid_ratios, int B,
+                            int S, int H, int C, int L, int Lq, int P, float *grad_value,
+                            float *grad_offsets, float *grad_ref_rows, float *grad_attn,
+                            const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
+                             const float *grid, const float *attn, const uint16_t *grad_out,
+                             const float *ref, int ref_dim, int ref_per_head, const float *offsets,
+                             int V, int angle_mode, const float *kernel_idx, const float *valid_ratios,
+                             int B, int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
+                             float *grad_offsets, float *grad_ref_rows, float *grad_attn,
+                             const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
+/*
  * ---- pointwise work around the operator (opt-in, beyond the reference's native module) ------
  * The modules' softmax over the L*P attention logits of every (query, head) and the zeroing of
  * padded value rows (reference e2edet/module/box_attention.py:222-231), as single passes:

@@ -995,3 +995,102 @@ def test_modules_with_fused_pointwise():
         assert (outs[0][0] - outs[1][0]).abs().max().item() <= tol * scale, cls.__name__
         for ga, gb in zip(outs[0][1], outs[1][1]):
             assert (ga - gb).abs().max().item() <= tol * max(1.0, ga.abs().max().item()), cls.__name__
+
+
+# ------------------------------------------------------------------ boxes straight into the kernels (N1, step 2)
+def _box_inputs(levels, B, H, angle_mode, per_head, with_ratio, dtype, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    shapes = torch.tensor(levels, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S, L, P, C = int(shapes.prod(1).sum()), len(levels), 4, 32
+    Lq = S
+    V = 5 if angle_mode == 1 else 4
+    D = 5 if angle_mode else 4
+    value = torch.randn(B, S, H, C, device="cuda", generator=g).to(dtype)
+    ref = torch.rand((B, Lq, H, D) if per_head else (B, Lq, D), device="cuda", generator=g)
+    ref[..., 2:4] = 0.02 + 0.1 * ref[..., 2:4]
+    off = torch.randn(B, Lq, H, L, V, device="cuda", generator=g)
+    kidx = torch.tensor([[-.25, -.25], [.25, -.25], [-.25, .25], [.25, .25]], device="cuda")
+    vr = (0.7 + 0.3 * torch.rand(B, 1, 1, L, 1, 2, device="cuda", generator=g)) if with_ratio else None
+    attn = torch.softmax(torch.randn(B, Lq, H, L * P, device="cuda", generator=g), -1).view(B, Lq, H, L, P)
+    gout = torch.randn(B, Lq, H * C, device="cuda", generator=g).to(dtype)
+    return value, shapes, lsi, ref, off, kidx, vr, attn, gout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("angle_mode,per_head,with_ratio",
+                         [(0, False, False), (0, False, True), (1, False, True), (2, True, False)])
+@pytest.mark.parametrize("levels", [[(80, 64), (40, 32), (20, 16), (10, 8)], [(96, 80), (48, 40)]],
+                         ids=["4lv", "2lv"])
+def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, dtype):
+    """boxattn_fwd_grid_* / boxattn_bwd_ws_grid_*: same grid as the grid kernel (bit-identical: same
+    operations), same output as the forward on that grid, and box gradients equal to
+    box_attn_backward followed by the grid kernel's backward."""
+    from boxer_amd import ops
+    value, shapes, lsi, ref, off, kidx, vr, attn, gout = _box_inputs(
+        levels, 2, 8, angle_mode, per_head, with_ratio, dtype)
+    res = ops.box_attn_forward_from_boxes(value, shapes, lsi, ref, off, kidx, vr, angle_mode, attn)
+    assert res is not None, "the fused forward should take this shape"
+    out, grid = res
+    want_grid = ops.box_grid_forward(ref, off, kidx, vr, angle_mode)
+    assert torch.equal(grid, want_grid)
+    assert torch.equal(out, ops.box_attn_forward(value, shapes, lsi, want_grid, attn, 64))
+    fused = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr,
+                                           angle_mode, need_ref_grad=True)
+    assert fused is not None, "the fused backward should take this shape"
+    gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, grid, attn, gout, 64)
+    go, rows = ops.box_grid_backward(ref, off, kidx, vr, angle_mode, gl, need_ref_grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused[3], ga)
+    # (grad_value: same kernels, but the summation order inside a bin differs from run to run)
+    for got, want, name in ((fused[0].float(), gv.float(), "grad_value"), (fused[1], go, "grad_offsets"),
+                            (fused[2], rows, "grad_ref_rows")):
+        err = (got - want).abs().max().item()
+        tol = 1e-2 if (name == "grad_value" and dtype == torch.bfloat16) else 1e-5
+        assert err <= tol * max(1.0, want.abs().max().item()), (name, err)
+
+
+def test_modules_with_grid_inside_the_kernels():
+    """``module.fused_grid = 2``: outputs and parameter gradients of BoxAttention / Box3dAttention
+    as without it -- on an encoder-sized map (the fused kernels run) and on a small decoder shape
+    (the Function falls back to the grid kernels + the plain operator)."""
+    from boxer_amd import Box3dAttention, BoxAttention
+    torch.manual_seed(0)
+    d = 256
+    for levels, Lq in (([(48, 40), (24, 20), (12, 10), (6, 5)], None), ([(12, 9), (6, 5)], 17)):
+        shapes = torch.tensor(levels, device="cuda")
+        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        S, nl = int(shapes.prod(1).sum()), len(levels)
+        B = 2
+        n_q = S if Lq is None else Lq
+        query = torch.randn(B, n_q, d, device="cuda")
+        value = torch.randn(B, S, d, device="cuda")
+        v_mask = torch.rand(B, S, device="cuda") < 0.1
+        ratios = 0.7 + 0.3 * torch.rand(B, 1, 1, nl, 1, 2, device="cuda")
+        ref = (torch.rand(B, n_q, 5, device="cuda") * 0.5 + 0.2).requires_grad_()
+        for cls, kw, native in ((BoxAttention, {}, False), (BoxAttention, {}, True),
+                                (Box3dAttention, {"with_rotation": True}, False),
+                                (Box3dAttention, {"with_rotation": False}, False)):
+            m = cls(d, nl, 8, **kw).cuda()
+            m.native_bf16 = native
+            with torch.no_grad():
+                m.linear_box_weight.normal_(0, 0.05)
+                m.linear_attn_weight.normal_(0, 0.05)
+            rw = ref if cls is Box3dAttention else ref[..., :4]
+            outs = []
+            for fused in (False, 2):
+                m.fused_grid = fused
+                m.zero_grad()
+                ref.grad = None
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native):
+                    res = m(query, value, shapes, v_mask, lsi, ratios, rw)
+                res[0].float().square().sum().backward()
+                outs.append((res[0].detach().float(), ref.grad.clone(),
+                             [p.grad.detach().clone() for p in m.parameters()]))
+            tol = 2e-2 if native else 2e-5
+            scale = max(1.0, outs[0][0].abs().max().item())
+            assert (outs[0][0] - outs[1][0]).abs().max().item() <= tol * scale, cls.__name__
+            assert (outs[0][1] - outs[1][1]).abs().max().item() <= tol * max(
+                1.0, outs[0][1].abs().max().item()), (cls.__name__, "ref grad")
+            for ga, gb in zip(outs[0][2], outs[1][2]):
+                assert (ga - gb).abs().max().item() <= tol * max(1.0, ga.abs().max().item()), cls.__name__
