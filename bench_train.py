@@ -14,7 +14,7 @@ class and box heads).  One process per GPU; gradients are all-reduced by Distrib
 (RCCL with backend "nccl", gloo in the CPU test) -- the operator itself never communicates.
 
   python bench_train.py [--steps 30 --warmup 10 --dtype bf16|fp32 --fused-grid --fused-pointwise
-                         --model 2d|3d --mask-decoder]
+                         --model 2d|3d --mask-decoder --split-k-wgrad --graph]
   python bench_train.py --gpus N          (starts its own N ranks; or under torch.distributed.run)
 prints ONE JSON line on rank 0: ms per step (MAX over ranks), images/s, operator share.
 """
@@ -124,6 +124,30 @@ def train_step(model, opt, batch, autocast_dtype=None):
     return loss.detach()
 
 
+def graphed_step(model, opt, batch, autocast_dtype):
+    """One training step as ONE HIP graph launch: the eager step is ~2 500 kernel launches and,
+    at BoxeR-2D shapes, as long on the host as on the GPU.  Warm-up on a side stream (allocator,
+    host copies of the level tables, optimizer state), then capture forward + backward +
+    optimizer step; the operator's entry points neither allocate nor read on the host, so they
+    capture like any other kernel launch.  Static shapes and buffers (the synthetic batch)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            train_step(model, opt, batch, autocast_dtype)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = train_step(model, opt, batch, autocast_dtype)
+
+    def replay():
+        graph.replay()
+        return loss
+    replay.graph = graph
+    return replay
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +158,12 @@ def main():
                     help="bf16: autocast for the dense layers + the operator's native bf16 mode")
     ap.add_argument("--fused-grid", nargs="?", const=1, default=0, type=int,
                     help="1: grid construction in one kernel each way; 2: inside the sampling kernels")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (forward, backward, optimizer) in one HIP graph "
+                         "(1 GPU; static synthetic batch)")
+    ap.add_argument("--split-k-wgrad", action="store_true",
+                    help="weight gradients of the S-long projections as batched split-K products "
+                         "(boxer_amd.dense)")
     ap.add_argument("--fused-pointwise", action="store_true",
                     help="softmax and value mask + cast as single HIP passes (module.fused_pointwise)")
     ap.add_argument("--mask-decoder", action="store_true",
@@ -173,29 +203,21 @@ def main():
         m.fused_pointwise = args.fused_pointwise
         with torch.no_grad():                                # trained-like box offsets
             m.linear_box_weight.normal_(0, 0.02)
+    from boxer_amd import dense
+    dense.set_split_k(args.split_k_wgrad)
     n_params = sum(p.numel() for p in model.parameters())
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    if args.graph and world > 1:
+        raise SystemExit("--graph captures a single-GPU step (the DDP all-reduce is not captured)")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=args.graph)
     batch = make_batch(levels, args.batch, 256, device, seed=100 + rank)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
 
     for _ in range(args.warmup):
         train_step(model, opt, batch, amp)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(model, opt, batch, amp)
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=device)
-    if dist is not None:
-        dist.barrier()
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    ms_step = float(elapsed) / args.steps * 1e3
-
-    # operator share: HIP events around every kernel launch of the library, two more steps
+    # operator share: HIP events around every kernel launch of the library, two eager steps
     _lib.profile_begin()
     for _ in range(2):
         train_step(model, opt, batch, amp)
@@ -203,13 +225,31 @@ def main():
     prof = _lib.profile_end()
     op_ms = sum((v["ms"] or 0.0) * v["launches"] for v in prof.values()) / 2
 
+    step = (lambda: train_step(model, opt, batch, amp)) if not args.graph else \
+        graphed_step(model, opt, batch, amp)
+    if args.graph:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=device)
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    ms_step = float(elapsed) / args.steps * 1e3
+
     if rank == 0:
         print(json.dumps({
             "metric": "synthetic BoxeR-%s training step (%d+%d layers, levels %s)" % (
                 args.model.upper(), args.layers, args.layers, "/".join("%dx%d" % hw for hw in levels)),
             "ms_per_step": round(ms_step, 3), "images_per_s": round(world * args.batch / ms_step * 1e3, 2),
             "n_gpus": world, "batch_per_gpu": args.batch, "dtype": args.dtype,
-            "fused_grid": args.fused_grid, "fused_pointwise": args.fused_pointwise, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
+            "fused_grid": args.fused_grid, "fused_pointwise": args.fused_pointwise, "split_k_wgrad": args.split_k_wgrad, "graph": args.graph, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
             "operator_kernels_ms_per_step": round(op_ms, 3),
             "operator_share": round(op_ms / ms_step, 3), "loss": round(float(loss), 4),
             "data": "synthetic", "scaling": "weak"}), flush=True)

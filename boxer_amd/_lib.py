@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_NAME = "libboxattn_hip.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
+INCLUDE_DIR = os.path.join(os.path.dirname(_PKG), "include")
 SOURCES = ["boxattn_capi.hip"]
 HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

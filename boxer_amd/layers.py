@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense
 from .modules import Box3dAttention, BoxAttention, InstanceAttention
 
 
@@ -46,7 +47,8 @@ class _LayerBase(nn.Module):
         self.activation = _activation(activation)
 
     def _ffn(self, x):
-        return self.linear2(self.dropout(self.activation(self.linear1(x))))
+        hidden = self.activation(dense.linear(x, self.linear1.weight, self.linear1.bias))
+        return dense.linear(self.dropout(hidden), self.linear2.weight, self.linear2.bias)
 
     def _self_attention(self, tgt, query_pos):
         """nn.MultiheadAttention over the object queries (sequence-first), residual + norm1."""

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense
 from .functions import (BoxAttnBF16Function, BoxAttnFromBoxesFunction, BoxAttnFunction, BoxGridFunction,
                         InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
                         ValueMaskCastFunction)
@@ -78,7 +79,7 @@ class _BoxAttentionBase(nn.Module):
     # -- pieces of forward -------------------------------------------------------------
     def _project_value(self, value, v_mask):
         b, s = value.shape[:2]
-        value = self.value_proj(value)
+        value = dense.linear(value, self.value_proj.weight, self.value_proj.bias)
         if (self.fused_pointwise and self.native_bf16 and value.is_cuda and
                 value.dtype in (torch.float32, torch.bfloat16) and self.d_model % 8 == 0 and
                 (v_mask is not None or value.dtype != torch.bfloat16)):   # else: nothing to do
@@ -96,7 +97,7 @@ class _BoxAttentionBase(nn.Module):
 
     def _box_offsets(self, query, ref_windows, n_vars):
         b, l = ref_windows.shape[:2]
-        off = F.linear(query, self.linear_box_weight, self.linear_box_bias)
+        off = dense.linear(query, self.linear_box_weight, self.linear_box_bias)
         return off.view(b, l, self.num_head, self.num_level, n_vars)
 
     @staticmethod
@@ -148,7 +149,7 @@ class BoxAttention(_BoxAttentionBase):
 
     def _softmax_weights(self, query):
         b, l1 = query.shape[:2]
-        w = F.linear(query, self.linear_attn_weight, self.linear_attn_bias)
+        w = dense.linear(query, self.linear_attn_weight, self.linear_attn_bias)
         w = self._softmax(w.view(b, l1, self.num_head, -1))
         return w.view(b, l1, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
 
@@ -167,7 +168,7 @@ class BoxAttention(_BoxAttentionBase):
             sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
             output = self._box_function().apply(value, v_shape, v_start_index, sampled_grid,
                                                 attn_weights, self.im2col_step)
-        return self.out_proj(output), attn_weights
+        return dense.linear(output, self.out_proj.weight, self.out_proj.bias), attn_weights
 
 
 class Box3dAttention(BoxAttention):
@@ -222,7 +223,7 @@ class InstanceAttention(_BoxAttentionBase):
         k = self.kernel_size
         value = self._project_value(value, v_mask)
 
-        logits = F.linear(query, self.linear_attn_weight, self.linear_attn_bias)
+        logits = dense.linear(query, self.linear_attn_weight, self.linear_attn_bias)
         logits = logits.view(b, l1, self.num_head, self.num_level, 2, 2)
         logits = logits.repeat_interleave(k // 2, dim=-1).repeat_interleave(k // 2, dim=-2)
         spatial_attn_weights = F.softmax(logits.reshape(b, l1, self.num_head, -1), dim=-1).view(

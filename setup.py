@@ -5,8 +5,10 @@
 
 Counterpart of the reference's setup.py:29-76 (CUDAExtension "e2edet.ops").  The product is a
 plain shared library with a C ABI (include/boxattn.h), not a torch extension module: PyTorch
-binds to it through ctypes (boxer_amd/ops.py), so the build needs neither torch headers nor
-pybind11 and works on a machine without a GPU (hipcc cross-compiles gfx950).
+binds to it through ctypes (boxer_amd/ops.py), so that part of the build needs neither torch
+headers nor pybind11 and works on a machine without a GPU (hipcc cross-compiles gfx950).  When
+torch is importable the build also compiles boxer_amd/csrc/e2edet_ops.cpp -- the reference's
+pybind11 module re-stated on the C ABI (four functions on at::Tensor, host code only).
 """
 import importlib.util
 import os
@@ -32,6 +34,15 @@ class build_hip(_build_ext):
         lib = _lib_module()
         path = lib.build(force=True, verbose=True)
         print("built", path)
+        # the reference's pybind11 module on the C ABI (host compiler + torch headers); optional:
+        # the package itself binds the library through ctypes
+        try:
+            import sys
+            sys.path.insert(0, HERE)
+            from boxer_amd import _ext
+            print("built", _ext.build(force=True, verbose=True))
+        except ImportError as e:
+            print("skipping the compiled e2edet_ops module (torch not importable):", e)
 
 
 setup(
@@ -39,7 +50,7 @@ setup(
     version="0.1.0",
     description="MI355X-native box-attention / instance-attention operator (BoxeR drop-in)",
     packages=find_packages(include=["boxer_amd", "boxer_amd.*"]),
-    package_data={"boxer_amd": ["libboxattn_hip.so", "csrc/*"]},
+    package_data={"boxer_amd": ["libboxattn_hip.so", "e2edet_ops*.so", "csrc/*"]},
     cmdclass={"build_ext": build_hip},
     python_requires=">=3.8",
 )

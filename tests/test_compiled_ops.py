@@ -1,0 +1,176 @@
+"""The compiled operator module (boxer_amd/csrc/e2edet_ops.cpp): the reference's pybind11 module
+``e2edet.ops`` (vision.cpp:7-12) on the C ABI.
+
+CPU: it builds with the host compiler, loads, exports the reference's four functions and refuses
+CPU tensors the way the reference does (box_attn.h:53 "Not implemented on the CPU").
+GPU: the four functions against the reference's golden vectors (fp64 / fp32 / bf16 storage), and
+autograd Functions written the way the reference writes them (``_C.box_attn_forward(...)`` in
+forward, ``_C.box_attn_backward(...)`` in backward, box_attention_func.py:9-64) running on it.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    from boxer_amd import _ext
+    _ext.build()
+    return _ext.load()
+
+
+def test_module_exports_the_reference_functions(compiled):
+    from boxer_amd import _ext, _lib
+    for name in _ext.FUNCTIONS:
+        assert callable(getattr(compiled, name)), name
+    assert compiled.abi_version() == _lib.ABI_VERSION
+
+
+def test_cpu_tensors_are_refused(compiled):
+    value = torch.zeros(1, 4, 1, 4)
+    shapes = torch.tensor([[2, 2]])
+    lsi = torch.zeros(1, dtype=torch.long)
+    loc = torch.zeros(1, 1, 1, 1, 1, 2)
+    attn = torch.ones(1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        compiled.box_attn_forward(value, shapes, lsi, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        compiled.instance_attn_forward(value, shapes, lsi, loc, attn, attn, 64)
+
+
+# ------------------------------------------------------------------ GPU
+TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 1e-2}
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def _close(got, want, tol, what):
+    got = got.detach().double().cpu().numpy()
+    want = np.asarray(want, dtype=np.float64).reshape(got.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max()) / scale
+    assert err <= tol, "%s: max scaled err %.3e > %.1e" % (what, err, tol)
+
+
+def _cdt(dtype):
+    return torch.float32 if dtype == torch.bfloat16 else dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["G1_box_reftest", "G3_box_C32", "G5_box_C1", "G6_box_ml"])
+def test_box_functions_match_goldens(compiled, name, dtype):
+    if dtype == torch.bfloat16 and name not in ("G5_box_C1", "G6_box_ml"):
+        pytest.skip("bf16 storage is pinned on the fixtures whose inputs are exact in bf16")
+    g = golden_io.load(name)
+    cdt = _cdt(dtype)
+    value, loc, attn = _dev(g["value"], dtype), _dev(g["loc"], cdt), _dev(g["attn"], cdt)
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    out = compiled.box_attn_forward(value, shapes, lsi, loc, attn, 64)
+    gv, gl, ga = compiled.box_attn_backward(value, shapes, lsi, loc, attn,
+                                            _dev(g["grad_out"], dtype), 64)
+    torch.cuda.synchronize()
+    assert out.dtype == dtype and gv.dtype == dtype and gl.dtype == cdt and ga.dtype == cdt
+    _close(out, g["out"], TOL[dtype], "out")
+    _close(gv, g["grad_value"], TOL[dtype], "grad_value")
+    _close(gl, g["grad_loc"], TOL[cdt], "grad_loc")
+    _close(ga, g["grad_attn"], TOL[cdt], "grad_attn")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["G2_inst_reftest", "G6_inst_ms4", "G6_inst_ms14"])
+def test_instance_functions_match_goldens(compiled, name, dtype):
+    if dtype == torch.bfloat16 and name == "G2_inst_reftest":
+        pytest.skip("bf16 storage is pinned on the fixtures whose inputs are exact in bf16")
+    g = golden_io.load(name)
+    cdt = _cdt(dtype)
+    value, loc = _dev(g["value"], dtype), _dev(g["loc"], cdt)
+    sw, lw = _dev(g["spatial_w"], cdt), _dev(g["level_w"], cdt)
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    gm = g["grad_mask"]
+    gmask = _dev(gm.reshape(gm.shape[0], gm.shape[1], -1, gm.shape[-1]), dtype)
+    out, mask = compiled.instance_attn_forward(value, shapes, lsi, loc, sw, lw, 64)
+    gv, gl, gs, glw = compiled.instance_attn_backward(value, shapes, lsi, loc, sw, lw,
+                                                      _dev(g["grad_out"], dtype), gmask, 64)
+    torch.cuda.synchronize()
+    _close(out, g["out"], TOL[dtype], "out")
+    _close(mask, g["mask_out"], TOL[dtype], "mask_out")
+    _close(gv, g["grad_value"], TOL[dtype], "grad_value")
+    _close(gl, g["grad_loc"], TOL[cdt], "grad_loc")
+    _close(gs, g["grad_spatial"], TOL[cdt], "grad_spatial")
+    _close(glw, g["grad_level"], TOL[cdt], "grad_level")
+
+
+@pytest.mark.gpu
+def test_same_results_as_the_ctypes_binding(compiled):
+    """Both bindings marshal into the same library: identical forward, grad_loc and grad_attn
+    bits; grad_value to float32 summation order."""
+    from boxer_amd import ops
+    g = golden_io.load("G6_box_ml")
+    value, loc, attn = (_dev(g[k], torch.float32) for k in ("value", "loc", "attn"))
+    shapes, lsi, gout = _dev(g["shapes"]), _dev(g["lsi"]), _dev(g["grad_out"], torch.float32)
+    a = compiled.box_attn_forward(value, shapes, lsi, loc, attn, 64)
+    b = ops.box_attn_forward(value, shapes, lsi, loc, attn, 64)
+    assert torch.equal(a, b)
+    ga = compiled.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64)
+    gb = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64)
+    assert torch.equal(ga[1], gb[1]) and torch.equal(ga[2], gb[2])
+    assert torch.allclose(ga[0], gb[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_error_behaviour(compiled):
+    g = golden_io.load("G6_box_ml")
+    value, loc, attn = (_dev(g[k], torch.float32) for k in ("value", "loc", "attn"))
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        compiled.box_attn_forward(value.transpose(2, 3), shapes, lsi, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        compiled.box_attn_forward(value.cpu(), shapes, lsi, loc, attn, 64)
+    b = value.size(0)
+    if b % 2 == 1:
+        value, loc, attn = (torch.cat([t, t]) for t in (value, loc, attn))
+    with pytest.raises(RuntimeError, match="must divide"):
+        compiled.box_attn_forward(torch.cat([value, value[:1]]), shapes, lsi,
+                                  torch.cat([loc, loc[:1]]), torch.cat([attn, attn[:1]]), 2)
+
+
+@pytest.mark.gpu
+def test_reference_style_function_on_the_compiled_module(compiled):
+    """An autograd Function in the reference's shape (forward saves the five tensors and calls
+    ``_C.box_attn_forward``; backward calls ``_C.box_attn_backward`` and returns
+    (grad_value, None, None, grad_loc, grad_attn, None)) passes gradcheck in float64 on it."""
+    from torch.autograd import Function, gradcheck
+    from torch.autograd.function import once_differentiable
+    _C = compiled
+
+    class RefStyleBoxAttn(Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+            ctx.im2col_step = im2col_step
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return _C.box_attn_forward(value, shapes, lsi, loc, attn, im2col_step)
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = _C.box_attn_backward(value, shapes, lsi, loc, attn,
+                                              grad_output.contiguous(), ctx.im2col_step)
+            return gv, None, None, gl, ga, None
+
+    shapes = torch.tensor([(6, 4), (3, 2)], dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(5)
+    value = (torch.rand(1, S, 2, 32, device="cuda", dtype=torch.double) * 0.01).requires_grad_()
+    loc = torch.rand(1, 2, 2, 2, 2, 2, device="cuda", dtype=torch.double).requires_grad_()
+    attn = torch.rand(1, 2, 2, 2, 2, device="cuda", dtype=torch.double) + 1e-5
+    attn = (attn / attn.sum((-1, -2), keepdim=True)).requires_grad_()
+    assert gradcheck(RefStyleBoxAttn.apply, (value, shapes, lsi, loc, attn, 2))

@@ -150,3 +150,59 @@ def test_bev_encoder_layer_runs_on_pillar_features():
     assert torch.isfinite(x.grad).all()
     err = (out.double() - want).abs().max().item()
     assert err <= 5e-2 * max(1.0, want.abs().max().item()), err
+
+
+def test_split_k_weight_gradient_matches_linear():
+    """boxer_amd.dense: the batched split-K weight gradient (and the bias gradient taken in the
+    same backward) equal F.linear's, ragged tail included."""
+    import torch.nn.functional as F
+    from boxer_amd import dense
+    torch.manual_seed(0)
+    x = torch.randn(3, 1111, 24, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(40, 24, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(40, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(3, 1111, 40, dtype=torch.float64)
+    want = torch.autograd.grad(F.linear(x, w, b), (x, w, b), g)
+    old = dense.CHUNK_ROWS
+    dense.CHUNK_ROWS = 256                          # 3333 rows: 13 chunks of 256 + a tail of 5
+    try:
+        y = dense._SplitKLinear.apply(x, w, b)
+        got = torch.autograd.grad(y, (x, w, b), g)
+    finally:
+        dense.CHUNK_ROWS = old
+    assert torch.allclose(y, F.linear(x, w, b))
+    for a, c in zip(got, want):
+        assert torch.allclose(a, c, rtol=1e-10, atol=1e-10)
+    # off (the default), on CPU or with few rows: plain F.linear
+    assert "SplitK" not in dense.linear(x, w, b).grad_fn.name()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False, True])
+def test_split_k_linear_on_gpu(amp):
+    """Same outputs; weight / bias gradients equal F.linear's to the rounding of the partial
+    products (bf16 under autocast), measured against a float64 reference."""
+    import torch.nn.functional as F
+    from boxer_amd import dense
+    torch.manual_seed(1)
+    x = torch.randn(2, 9000, 256, device="cuda", requires_grad=True)
+    w = (0.05 * torch.randn(128, 256, device="cuda")).requires_grad_()
+    b = torch.randn(128, device="cuda", requires_grad=True)
+    g = torch.randn(2, 9000, 128, device="cuda")
+    ref = torch.autograd.grad(F.linear(x.double(), w.double(), b.double()), (x, w, b), g.double())
+    old = dense.set_split_k(True)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = dense.linear(x, w, b)
+            y0 = F.linear(x, w, b)
+        assert "SplitK" in y.grad_fn.name()
+        got = torch.autograd.grad(y, (x, w, b), g.to(y.dtype))
+        base = torch.autograd.grad(y0, (x, w, b), g.to(y0.dtype))
+    finally:
+        dense.set_split_k(old)
+    assert y.dtype == y0.dtype and torch.equal(y, y0)
+    for a, c, r in zip(got, base, ref):
+        assert a.dtype == c.dtype
+        scale = float(r.abs().max())
+        err_new, err_lib = float((a.double() - r).abs().max()), float((c.double() - r).abs().max())
+        assert err_new <= max(2.0 * err_lib, (4e-3 if amp else 2e-5) * scale), (err_new, err_lib)
