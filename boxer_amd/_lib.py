@@ -171,7 +171,8 @@ def set_variant(v):
 
 
 OPTIONS = {"tile_shape": 0, "tile_rows": 1, "tile_margin_cap": 2, "tile_static_q16": 3,
-           "tile_ablate": 4, "qg_target": 5, "tile_fwd": 6, "qg_ablate": 7, "qg_waves": 8, "qg_bwd": 9}
+           "tile_ablate": 4, "qg_target": 5, "tile_fwd": 6, "qg_ablate": 7, "qg_waves": 8, "qg_bwd": 9,
+           "bin_chunk": 10}
 
 
 def set_option(name, value):

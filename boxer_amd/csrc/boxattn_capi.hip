@@ -34,7 +34,8 @@ std::atomic<int> g_variant{0};
 
 // Tuning options (boxattn_set_option): process-wide knobs for A/B runs, relaxed atomics.
 enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStatic = 3, kOptTileAblate = 4,
-       kOptQgTarget = 5, kOptTileFwd = 6, kOptQgAblate = 7, kOptQgWaves = 8, kOptQgBwd = 9, kNumOpts = 12 };
+       kOptQgTarget = 5, kOptTileFwd = 6, kOptQgAblate = 7, kOptQgWaves = 8, kOptQgBwd = 9, kOptBinChunk = 10,
+       kNumOpts = 12 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
@@ -575,7 +576,20 @@ struct SideStream {
 #ifndef BOXATTN_TUNE_CHUNK
 #define BOXATTN_TUNE_CHUNK 1024
 #endif
-constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item
+constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item (upper bound)
+// Records per work item.  One wavefront works an item off 64 records a round, and a round is a
+// chain of dependent latencies (~3-5 us), so the kernel lasts at least rounds-per-item rounds:
+// with few sample points (the decoders: 300 queries) 1 024-record items leave a handful of waves
+// running 16 rounds while the rest of the chip idles.  Aim at ~256 items per (image, head) slice
+// -- about the wave slots a slice gets -- between 128 and kChunk records.
+inline int bin_chunk(const Dims &d)
+{
+    const int forced = opt(kOptBinChunk);
+    if (forced > 0) return std::min(4096, std::max(64, (forced + 63) / 64 * 64));
+    const long long rec_est = 3ll * d.Lq * d.L * d.P / 2;          // ~1.4 records per point
+    const long long c = (rec_est / 256 + 63) / 64 * 64;
+    return (int)std::min<long long>(kChunk, std::max<long long>(128, c));
+}
 // One stream by default.  Running the point-gradient kernel (and, in the training forward, the
 // bin passes) on the library's helper stream once paid for fp32 storage (C2: 283 -> 270 us per
 // step); with the faster bin passes it no longer does (C2 fp32 278 us on one stream, 283 on
@@ -664,10 +678,10 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     p.n_slices = d.B * d.H;
     p.nblk = (int)blk0;
     p.rec_cap = (int)rec_cap;
-    p.chunk = kChunk;
-    p.item_cap = (int)(blk0 + rec_cap / kChunk + 1);
+    p.chunk = bin_chunk(d);
+    p.item_cap = (int)(blk0 + rec_cap / p.chunk + 1);
     // blocks with more than one chunk: sum of their chunk counts <= 2 * records / chunk
-    p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / kChunk) + 2, blk0 + rec_cap / kChunk + 1);
+    p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / p.chunk) + 2, blk0 + rec_cap / p.chunk + 1);
     return true;
 }
 

@@ -43,6 +43,11 @@ constexpr unsigned kOobOffset = 0x80000000u;     // >= any valid byte offset (te
 #ifndef BOXATTN_TUNE_PREFETCH
 #define BOXATTN_TUNE_PREFETCH 1   // locations / weights of tile t+1 are requested during tile t
 #endif
+#ifndef BOXATTN_TUNE_PRELOAD
+#define BOXATTN_TUNE_PRELOAD 1    // L P == 4 G: the locations / weights of all tiles up front
+#endif
+constexpr bool kGatherPreload = BOXATTN_TUNE_PRELOAD != 0;
+constexpr int kPreTiles = 4;
 constexpr bool kGatherSched = BOXATTN_TUNE_SCHED != 0;
 constexpr bool kGatherPrefetch = BOXATTN_TUNE_PREFETCH != 0;
 __device__ __forceinline__ void loads_issued()
@@ -117,9 +122,21 @@ __device__ __forceinline__ f32x2 row_pair(const Row<ST, VEC> &v, int i)
 }
 
 // acc (VEC / 2 channel pairs) += w * row
+#ifndef BOXATTN_TUNE_FWD_ABLATE
+#define BOXATTN_TUNE_FWD_ABLATE 0   // timing experiments only (wrong results): 1 = the rows are
+#endif                              // consumed by one XOR per word instead of unpack + FMA,
+                                    // 2 = every row load hits the first 4 KiB of value (L1 hits),
+                                    // 3 = no row loads
 template <typename ST, int VEC>
 __device__ __forceinline__ void row_axpy(f32x2 (&acc)[VEC / 2], float w, const Row<ST, VEC> &v)
 {
+    if constexpr (BOXATTN_TUNE_FWD_ABLATE == 1 && sizeof(ST) == 2) {
+#pragma unroll
+        for (int i = 0; i < VEC / 2; ++i)
+            acc[i].x = __uint_as_float(__float_as_uint(acc[i].x) ^ v.w[i]);
+        acc[0].y = __uint_as_float(__float_as_uint(acc[0].y) ^ __float_as_uint(w));
+        return;
+    }
     const f32x2 w2 = {w, w};
 #pragma unroll
     for (int i = 0; i < VEC / 2; ++i)
@@ -306,28 +323,16 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     for (int i = 0; i < VEC / 2; ++i) acc[i] = f32x2{0.f, 0.f};
 
     if constexpr (!INST) {
-        float2 xy_n = make_float2(0.f, 0.f);
-        if constexpr (!GRID) xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
-        float a_n = w_sp[pt0 + min(slot, LP - 1)];
-        for (int t0 = 0; t0 < LP; t0 += G) {
+        // one tile: G points of every pair of the wave.  xy / a: location and weight of THIS
+        // lane's point of the tile (point t0 + slot; ignored past the end)
+        auto tile = [&](int t0, float2 xy, float a_in) {
             u32x4_t my_off = {0u, 0u, 0u, 0u}, my_wt = {0u, 0u, 0u, 0u};
             {   // ---- step A
                 const int lp = t0 + slot;
                 const bool have = lp < LP;
                 const int lq = have ? lp : LP - 1;
                 const int l = (int)(((float)lq + 0.5f) * rcp_p);   // lq / P (exact, see rcp_p)
-                float2 xy;
-                float a;
-                if constexpr (kGatherPrefetch) {
-                    xy = xy_n;
-                    a = have ? a_n : 0.f;
-                    const int nq = min(lp + G, LP - 1);           // same point again past the end
-                    if constexpr (!GRID) xy_n = loc2[pt0 + nq];
-                    a_n = w_sp[pt0 + nq];
-                } else {
-                    if constexpr (!GRID) xy = loc2[pt0 + lq];
-                    a = have ? w_sp[pt0 + lq] : 0.f;
-                }
+                const float a = have ? a_in : 0.f;
                 if constexpr (GRID) {                             // the point from its box
                     const GridBox gb = grid_box(gs.ref, gs.offsets, gs.vr, gs.d, (size_t)qh * L + l);
                     xy = grid_point(gb, gs.kidx, lq - l * P, gs.vr != nullptr, gs.d.angle_mode);
@@ -362,6 +367,16 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                         off[u] = geo[(tb + u) * NH];
                         wt[u] = geo[(tb + u) * NH + 1];
                     }
+                    if constexpr (BOXATTN_TUNE_FWD_ABLATE == 2) {
+                        off[u].x &= 0xfc0u; off[u].y &= 0xfc0u; off[u].z &= 0xfc0u; off[u].w &= 0xfc0u;
+                    }
+                    if constexpr (BOXATTN_TUNE_FWD_ABLATE == 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int i = 0; i < RowT::NW; ++i) v[u][k].w[i] = off[u][k] + i;
+                        continue;
+                    }
                     row_load<ST, VEC, PSB>(rs, off[u].x + lane_off, v[u][0]);
                     row_load<ST, VEC, PSB>(rs, off[u].y + lane_off, v[u][1]);
                     row_load<ST, VEC, PSB>(rs, off[u].z + lane_off, v[u][2]);
@@ -375,6 +390,50 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                     row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].z), v[u][2]);
                     row_axpy<ST, VEC>(acc, __uint_as_float(wt[u].w), v[u][3]);
                 }
+            }
+        };
+        // The locations / weights of a wave are one contiguous run (64 / G pairs x L P points),
+        // but a lane only ever has its next tile's 12 bytes in flight: with one tile of
+        // look-ahead the kernel ran at the HBM LATENCY of that stream (4 dependent round trips
+        // per wave, 1.6 TB/s on 54 MB).  BoxeR's shape (L P = 4 G: 4 levels x 2 x 2 points, 4
+        // lanes per pair) requests all four tiles up front -- one round trip per wave.
+        if (kGatherPreload && !GRID && G == 4 && LP == kPreTiles * G) {
+            float2 xy4[kPreTiles];
+            float a4[kPreTiles];
+#pragma unroll
+            for (int k = 0; k < kPreTiles; ++k) {
+                xy4[k] = loc2[pt0 + k * G + slot];
+                a4[k] = w_sp[pt0 + k * G + slot];
+            }
+            // a rolled loop over the tiles (the registers rotate): unrolled, the scheduler pulls
+            // the row loads of all four tiles to the front (299 VGPRs)
+#pragma unroll 1
+            for (int t0 = 0; t0 < kPreTiles * G; t0 += G) {
+                tile(t0, xy4[0], a4[0]);
+#pragma unroll
+                for (int k = 0; k + 1 < kPreTiles; ++k) {
+                    xy4[k] = xy4[k + 1];
+                    a4[k] = a4[k + 1];
+                }
+            }
+        } else {
+            float2 xy_n = make_float2(0.f, 0.f);
+            if constexpr (!GRID) xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
+            float a_n = w_sp[pt0 + min(slot, LP - 1)];
+            for (int t0 = 0; t0 < LP; t0 += G) {
+                float2 xy = xy_n;
+                float a = a_n;
+                const int lp = t0 + slot;
+                if constexpr (kGatherPrefetch) {
+                    const int nq = min(lp + G, LP - 1);           // same point again past the end
+                    if constexpr (!GRID) xy_n = loc2[pt0 + nq];
+                    a_n = w_sp[pt0 + nq];
+                } else {
+                    const int lq = min(lp, LP - 1);
+                    if constexpr (!GRID) xy = loc2[pt0 + lq];
+                    a = w_sp[pt0 + lq];
+                }
+                tile(t0, xy, a);
             }
         }
     } else {
@@ -664,6 +723,21 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     float2 xy_n = loc2[pt0 + min(t_begin + slot, LP - 1)];      // first tile
     float as_n = w_sp[pt0 + min(t_begin + slot, LP - 1)];
     float al_n = INST ? w_lv[pt0 + min(t_begin + slot, LP - 1)] : 0.f;
+    // BoxeR's shape (L P = 4 G): all four tiles' locations / weights are requested up front,
+    // one HBM round trip per wave instead of one per tile (see fwd2_kernel)
+    constexpr bool kCanPre = kGatherPreload && !INST && !WP && G == 4;
+    const bool pre = kCanPre && gridDim.y == 1 && LP == kPreTiles * G;
+    float2 xyq[kCanPre ? kPreTiles - 1 : 1];
+    float asq[kCanPre ? kPreTiles - 1 : 1];
+#pragma unroll
+    for (int k = 0; k < (kCanPre ? kPreTiles - 1 : 1); ++k) {
+        xyq[k] = make_float2(0.f, 0.f);
+        asq[k] = 0.f;
+        if (pre) {
+            xyq[k] = loc2[pt0 + (k + 1) * G + slot];
+            asq[k] = w_sp[pt0 + (k + 1) * G + slot];
+        }
+    }
     const bool buffered = kCanBuffer && !WP && gridDim.y == 1 && (LP == 16 || LP == 8) &&
                           (((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0 ||
                            GRID);      // (GRID: the host has checked; grad_loc is not used)
@@ -679,10 +753,20 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
         float as, al;
         if constexpr (kGatherPrefetch) {
             xy = xy_n; as = as_n; al = al_n;
-            const int nq = min(lp + t_step, LP - 1);
-            xy_n = loc2[pt0 + nq];
-            as_n = w_sp[pt0 + nq];
-            al_n = INST ? w_lv[pt0 + nq] : 0.f;
+            if (kCanPre && pre) {
+                xy_n = xyq[0];
+                as_n = asq[0];
+#pragma unroll
+                for (int k = 0; k + 1 < (kCanPre ? kPreTiles - 1 : 1); ++k) {
+                    xyq[k] = xyq[k + 1];
+                    asq[k] = asq[k + 1];
+                }
+            } else {
+                const int nq = min(lp + t_step, LP - 1);
+                xy_n = loc2[pt0 + nq];
+                as_n = w_sp[pt0 + nq];
+                al_n = INST ? w_lv[pt0 + nq] : 0.f;
+            }
         } else {
             xy = loc2[pt0 + lq];
             as = w_sp[pt0 + lq];

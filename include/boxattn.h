@@ -336,6 +336,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *   8  query-grid backward: persistent waves per XCD (default 384)
  *   9  query-grid backward: 1 = use it for bf16 box attention with Lq == S (default off: measured
  *      slower than the binned backward)
+ *  10  binned backward: records per work item (multiple of 64; default: from the number of sample
+ *      points, 128 ... 1024).  Set it before boxattn_bwd_workspace_bytes: the workspace layout
+ *      depends on it.
  */
 int boxattn_set_option(int key, int value);
 
