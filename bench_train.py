@@ -251,6 +251,7 @@ def main():
             "n_gpus": world, "batch_per_gpu": args.batch, "dtype": args.dtype,
             "fused_grid": args.fused_grid, "fused_pointwise": args.fused_pointwise, "split_k_wgrad": args.split_k_wgrad, "graph": args.graph, "mask_decoder": args.mask_decoder, "params_M": round(n_params / 1e6, 2),
             "operator_kernels_ms_per_step": round(op_ms, 3),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "operator_share": round(op_ms / ms_step, 3), "loss": round(float(loss), 4),
             "data": "synthetic", "scaling": "weak"}), flush=True)
     if dist is not None:

@@ -87,6 +87,17 @@ __device__ __forceinline__ BlockGeo unpack_block_geo(unsigned g)
 #ifndef BOXATTN_TUNE_INTERLEAVE
 #define BOXATTN_TUNE_INTERLEAVE 1
 #endif
+// Which slices (image, head) an XCD's accumulate workers take: CONSECUTIVE ones (1), i.e. with
+// two slices per XCD the heads 2j and 2j + 1 of one image -- the two 64-byte (bf16) halves of
+// every 128-byte line of grad_out they read and of grad_value they write then meet in ONE L2 --
+// or every 8th (0: head x of every image, the round-1 mapping: half lines in two L2s).
+#ifndef BOXATTN_TUNE_SLICE_MAP
+#define BOXATTN_TUNE_SLICE_MAP 1
+#endif
+__device__ __forceinline__ int slice_on_xcd(int xcd, int i, int per_xcd)
+{
+    return BOXATTN_TUNE_SLICE_MAP ? xcd * per_xcd + i : xcd + 8 * i;
+}
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // bin_scan_a_kernel: sub-ranges of workgroups
 constexpr int kMaxBinLevels = 8;   // levels the binned backward plans for (BoxeR uses 2-5)
 
@@ -373,6 +384,120 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
     }
 }
 
+// Maps with more than kScanThreads blocks per slice (a 468 x 468 BEV level: 6 903): the same
+// scan over SEVERAL workgroups per slice.  One workgroup walking the blocks 1 024 at a time is
+// ~100 k uncoalesced 4-byte accesses through a single CU's memory pipeline (35 us at 6 903
+// blocks, the longest kernel of the BEV decoder's backward but one); here every segment of 1 024
+// blocks has its own workgroup, in two launches:
+//   bin_scan_seg_kernel   grid (segments, slices): per block the sub-range prefix (as above), the
+//                         block's record count -> offsets[] (scratch use), its exclusive prefixes
+//                         INSIDE the segment -> tmp[], the segment's four totals -> segtot[];
+//   bin_scan_emit_kernel  same grid: segment base = sum of the preceding segments' totals, then
+//                         offsets / items / combos exactly as bin_scan_kernel writes them.
+__global__ __launch_bounds__(kScanThreads) void bin_scan_seg_kernel(int *__restrict__ subtot,
+                                                                    int *__restrict__ offsets,
+                                                                    int4 *__restrict__ tmp,
+                                                                    int4 *__restrict__ segtot,
+                                                                    BinPlan plan)
+{
+    __shared__ int wsum[4][kScanThreads / 64];
+    const int seg = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = seg * kScanThreads + (int)threadIdx.x;
+    const bool live = k < plan.nblk;
+    int c = 0;
+    if (live) {
+        int t[kScanSub];
+#pragma unroll
+        for (int u = 0; u < kScanSub; ++u) t[u] = subtot[((size_t)s * kScanSub + u) * plan.nblk + k];
+#pragma unroll
+        for (int u = 0; u < kScanSub; ++u) {
+            subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;
+            c += t[u];
+        }
+    }
+    const int nch = live ? max(1, (c + plan.chunk - 1) / plan.chunk) : 0;
+    const int v[4] = {c, nch, nch > 1 ? nch : 0, nch > 1 ? 1 : 0};
+    int inc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x = v[i];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(x, o, 64);
+            if (lane >= o) x += t;
+        }
+        inc[i] = x;
+        if (lane == 63) wsum[i][wv] = x;
+    }
+    __syncthreads();
+    int ex[4], tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; ++w) {
+            pre += w < wv ? wsum[i][w] : 0;
+            all += wsum[i][w];
+        }
+        ex[i] = pre + inc[i] - v[i];
+        tot[i] = all;
+    }
+    if (live) {
+        offsets[(size_t)s * (plan.nblk + 1) + k] = c;                 // scratch: the emit kernel reads it
+        tmp[(size_t)s * plan.nblk + k] = make_int4(ex[0], ex[1], ex[2], ex[3]);
+    }
+    if (threadIdx.x == 0)
+        segtot[(size_t)s * gridDim.x + seg] = make_int4(tot[0], tot[1], tot[2], tot[3]);
+}
+
+__global__ __launch_bounds__(kScanThreads) void bin_scan_emit_kernel(int *__restrict__ offsets,
+                                                                     const int4 *__restrict__ tmp,
+                                                                     const int4 *__restrict__ segtot,
+                                                                     int4 *__restrict__ items,
+                                                                     int4 *__restrict__ combos,
+                                                                     int *__restrict__ n_items,
+                                                                     BinPlan plan)
+{
+    const int seg = blockIdx.x, s = blockIdx.y;
+    int base[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};
+    for (int g = 0; g < (int)gridDim.x; ++g) {                         // <= kMaxBlocks / kScanThreads
+        const int4 t = segtot[(size_t)s * gridDim.x + g];
+        const int tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            base[i] += g < seg ? tv[i] : 0;
+            all[i] += tv[i];
+        }
+    }
+    const int k = seg * kScanThreads + (int)threadIdx.x;
+    if (k < plan.nblk) {
+        const int c = offsets[(size_t)s * (plan.nblk + 1) + k];
+        const int4 e = tmp[(size_t)s * plan.nblk + k];
+        const int ex[4] = {base[0] + e.x, base[1] + e.y, base[2] + e.z, base[3] + e.w};
+        const int nch = max(1, (c + plan.chunk - 1) / plan.chunk);
+        offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
+        int level = 0;
+#pragma unroll
+        for (int l = 1; l < kMaxBinLevels; ++l)
+            if (l < plan.L && k >= plan.lv[l].blk0) level = l;
+        BinLevel lv = plan.lv[0];
+#pragma unroll
+        for (int l = 1; l < kMaxBinLevels; ++l)
+            if (l == level) lv = plan.lv[l];
+        const int geo = (int)pack_block_geo(lv, level, k);
+        for (int j = 0; j < nch; ++j)
+            items[(size_t)s * plan.item_cap + ex[1] + j] =
+                make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
+                          nch > 1 ? ex[2] + j : -1);
+        if (nch > 1) combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
+    }
+    if (seg == 0 && threadIdx.x == 0) {
+        offsets[(size_t)s * (plan.nblk + 1) + plan.nblk] = all[0];
+        n_items[2 * s] = all[1];
+        n_items[2 * s + 1] = all[3];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 5: accumulate.  One WAVEFRONT per work item (64-thread workgroups, no cross-wave barriers):
 //    every wave has private LDS and runs independently, so the many dependent latencies of an
@@ -448,7 +573,7 @@ void binned_accumulate_kernel(
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = bid % 8, k = bid / 8;
     const int per_xcd = (n_slices + 7) / 8;                 // slices handled by one XCD
-    const int s = xcd + 8 * (k % per_xcd);
+    const int s = slice_on_xcd(xcd, k % per_xcd, per_xcd);
     const int worker = k / per_xcd;                         // 0 .. workers-1 (grid is 8-aligned)
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
@@ -469,10 +594,14 @@ void binned_accumulate_kernel(
     // balancing.  (A software queue was slower both ways it was tried: with the 16 queue heads
     // in one cache line every dequeue of the chip serialised on that line -- 13 k atomics =
     // 160 us --, and with padded heads the dequeue round trip still cost 10 %.)
+    const int4 *my_items = items + (size_t)s * plan.item_cap;
+    int4 item_n = worker < n_it ? my_items[n_it - 1 - worker] : make_int4(0, 0, 0, 0);
     for (int it = worker; it < n_it; it += workers) {
         // coarse levels sit at the end of the list and carry the long chunked items: take
-        // them first so the tail of the kernel is made of short items
-        const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];
+        // them first so the tail of the kernel is made of short items (the next item of this
+        // workgroup is requested while it works on the current one)
+        const int4 item = item_n;
+        if (it + workers < n_it) item_n = my_items[n_it - 1 - (it + workers)];
         const BlockGeo bg = unpack_block_geo((unsigned)item.x);
         BinLevel lv = plan.lv[0];                    // select, no dynamic indexing of kernel args
 #pragma unroll

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = bid % 8, kq = bid / 8;
     const int per_xcd = (n_slices + 7) / 8;
-    const int s = xcd + 8 * (kq % per_xcd);
+    const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
     const int worker = kq / per_xcd;
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
@@ -112,8 +112,13 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
         for (int i = lane; i < CP * GS / 2; i += 64) reinterpret_cast<unsigned int *>(gt)[i] = 0u;
     wave_lds_sync();
 
+    // (a workgroup with several items -- big, mostly empty maps -- has its next item in flight while
+    // it works on the current one: an empty block is otherwise one dependent load per 2 KB stored)
+    const int4 *my_items = items + (size_t)s * plan.item_cap;
+    int4 item_n = worker < n_it ? my_items[n_it - 1 - worker] : make_int4(0, 0, 0, 0);
     for (int it = worker; it < n_it; it += workers) {
-        const int4 item = items[(size_t)s * plan.item_cap + (n_it - 1 - it)];   // heaviest first
+        const int4 item = item_n;                                               // heaviest first
+        if (it + workers < n_it) item_n = my_items[n_it - 1 - (it + workers)];
         const BlockGeo bg = unpack_block_geo((unsigned)item.x);
         BinLevel lv = plan.lv[0];
 #pragma unroll

@@ -632,7 +632,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
     size_t n_items;
-    size_t part, subtot, offsets, items, combos, records, partials, total;
+    size_t part, subtot, offsets, items, combos, records, partials, scan_tmp, total;
     int q_per_wg, n_wg;                                     // launch geometry of the bin passes
 };
 
@@ -718,6 +718,10 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
     w.combos = o;  o += align_up(ns * (size_t)p.nblk * 16);
     w.records = o; o += align_up(ns * (size_t)p.rec_cap * (wide ? 16 : 4));
     w.partials = o; o += align_up(ns * (size_t)p.pslot_cap * 32 * d.C * 4);
+    // multi-workgroup block scan (more than kScanThreads blocks per slice): per-block prefixes
+    // inside a segment + the segments' totals
+    w.scan_tmp = o;
+    if (p.nblk > kScanThreads) o += align_up(ns * ((size_t)p.nblk + kMaxBlocks / kScanThreads) * 16);
     w.total = o;
     return w;
 }
@@ -773,8 +777,17 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
     hipLaunchKernelGGL(bin_scan_a_kernel,
                        dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
                        part, w.n_wg, subtot, plan);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items,
-                       combos, n_items, plan);
+    if (plan.nblk > kScanThreads) {                  // big maps: the block scan over several CUs
+        const int nseg = (plan.nblk + kScanThreads - 1) / kScanThreads;
+        int4 *tmp = (int4 *)(ws + w.scan_tmp), *segtot = tmp + (size_t)ns * plan.nblk;
+        hipLaunchKernelGGL(bin_scan_seg_kernel, dim3(nseg, ns), dim3(kScanThreads), 0, st, subtot,
+                           offsets, tmp, segtot, plan);
+        hipLaunchKernelGGL(bin_scan_emit_kernel, dim3(nseg, ns), dim3(kScanThreads), 0, st, offsets,
+                           tmp, segtot, items, combos, n_items, plan);
+    } else {
+        hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets,
+                           items, combos, n_items, plan);
+    }
     BOXATTN_BIN(true);
 #undef BOXATTN_BIN
 }
@@ -889,7 +902,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // kernel maps workgroups to (slice, worker) itself (XCD affinity), hence the 8-aligned grid.
     const int ns8 = (ns + 7) / 8 * 8;
 #ifndef BOXATTN_TUNE_ACC_WG_CAP
-#define BOXATTN_TUNE_ACC_WG_CAP 3072   // per slice; beyond that a workgroup takes several items (big, mostly empty maps)
+#define BOXATTN_TUNE_ACC_WG_CAP 1024   // per slice; beyond that a workgroup takes several items (its next one in flight);
+                                       // 256 / 512 / 1024 / 3072 / 6144: C5 99 / 85 / 83 / 93 / 111 us, C2 67 / 54 / 54 / 55 / 54
 #endif
     const int wg_per_slice = BOXATTN_TUNE_ACC_WG_CAP
                                  ? std::min(BOXATTN_TUNE_ACC_WG_CAP, std::max(1, plan.item_cap))
