@@ -20,10 +20,20 @@ for cfg in "C2_bf16_model" "C2_fp32_model --dtype fp32" "C2_bf16_test --inputs t
   rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
 done
 bash tools/gpu_workloads.sh > $R/workloads.log 2>&1
-for args in "" "--fused-grid" "--fused-grid --fused-pointwise" "--dtype fp32" "--mask-decoder" "--model 3d" "--model 3d --fused-grid --fused-pointwise"; do
+rm -f $R/train_step.log
+for args in "" "--fused-grid 1" "--fused-grid 1 --fused-pointwise" "--fused-grid 2 --fused-pointwise" \
+            "--fused-grid 1 --fused-pointwise --split-k-wgrad" "--graph" \
+            "--fused-grid 1 --fused-pointwise --split-k-wgrad --graph" "--dtype fp32" \
+            "--dtype fp32 --fused-grid 1 --fused-pointwise --split-k-wgrad --graph" "--mask-decoder" \
+            "--mask-decoder --fused-grid 1 --fused-pointwise --split-k-wgrad --graph" "--model 3d" \
+            "--model 3d --fused-grid 1 --fused-pointwise --split-k-wgrad" \
+            "--model 3d --fused-grid 1 --fused-pointwise --split-k-wgrad --graph"; do
   echo "bench_train.py $args" >> $R/train_step.log
-  timeout 600 python bench_train.py --steps 10 --warmup 4 $args 2>/dev/null | tail -1 >> $R/train_step.log
+  timeout 600 python bench_train.py $args 2>/dev/null | tail -1 >> $R/train_step.log
 done
+python tools/gpu_module_bench.py 2>/dev/null | grep -v amdgpu > $R/module_bench.log
+python tools/gpu_chunk_sweep.py C3 C3pp C5 2>/dev/null | grep -v amdgpu > $R/chunk_sweep.log
+bash tools/gpu_pmc.sh r02sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" > $R/pmc_sq.txt 2>&1
 # the opt-in query-grid experiments next to the defaults
 python tools/gpu_tile_bench.py C2 fwd 2>/dev/null | grep -v amdgpu > $R/experiment_tile_forward.log
 python tools/gpu_qg_bench.py C2 model 2>/dev/null | grep -v amdgpu > $R/experiment_qgrid_backward.log
