@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     }
     const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in bin_scan_a_kernel
     const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
-    for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x)
+    for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads)
         hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
     __syncthreads();
 
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     const float rcp_lpg = 1.0f / (float)LPG, rcp_p = 1.0f / (float)P;
     int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
     (void)n_pts;
-    for (int g0 = threadIdx.x; g0 < n_grp; g0 += blockDim.x * U) {
+    for (int g0 = threadIdx.x; g0 < n_grp; g0 += kBinThreads * U) {
         float2 xy[U][PT];
         float wv[U][PT];
         int lp0[U], ql[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int g = min(g0 + u * (int)blockDim.x, n_grp - 1);
+            const int g = min(g0 + u * kBinThreads, n_grp - 1);
             int lg;
             divmod_small(g, LPG, rcp_lpg, ql[u], lg);
             lp0[u] = lg * PT;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (g0 + u * (int)blockDim.x >= n_grp) break;
+            if (g0 + u * kBinThreads >= n_grp) break;
             const BinLevel lv = s_lv[(int)(((float)lp0[u] + 0.5f) * rcp_p)];   // level = lp / P
 #pragma unroll
             for (int k = 0; k < PT; ++k) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     }
     if (!FILL) {
         __syncthreads();
-        for (int k = threadIdx.x; k < plan.nblk; k += blockDim.x) mypart[k] = hist[k];
+        for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads) mypart[k] = hist[k];
     }
 }
 

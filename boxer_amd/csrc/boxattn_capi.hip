@@ -135,6 +135,14 @@ inline int gather_blocks(const Dims &d, const GatherIdx &ix, int pairs)
     if (ix.head_xcd) return 8 * ceil_div_sz((size_t)d.B * d.Lq, (size_t)pairs * 4);
     return ceil_div_sz(d.n_qh(), (size_t)pairs * 4);
 }
+// the launch geometry as explicit kernel arguments (GatherIdx: grid_x, grid_y, tps)
+inline GatherIdx with_grid(GatherIdx ix, int grid_x, int grid_y, int tiles)
+{
+    ix.grid_x = (unsigned)grid_x;
+    ix.grid_y = (unsigned)std::max(1, grid_y);
+    ix.tps = (unsigned)((tiles + (int)ix.grid_y - 1) / (int)ix.grid_y);
+    return ix;
+}
 // (the 8-channel kernels are only instantiated for the storage types that select them)
 template <typename ST> struct GatherVec8 {
     static constexpr bool value = (sizeof(ST) == 2 ? BOXATTN_TUNE_VEC_BF16 : BOXATTN_TUNE_VEC_F32) == 8;
@@ -364,7 +372,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 #define BOXATTN_FWD_WIDE(GG, VV)                                                              \
     hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(wblocks), dim3(256), 0, st,   \
                        value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out,    \
-                       mask, ix, (unsigned)vbytes);
+                       mask, with_grid(ix, wblocks, 1, 1), (unsigned)vbytes);
                     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD_WIDE);
 #undef BOXATTN_FWD_WIDE
                     return finish();
@@ -374,7 +382,8 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 #define BOXATTN_FWD2(GG, VV)                                                                  \
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
                        dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
-                       w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask, ix, (unsigned)vbytes);
+                       w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask,                             \
+                       with_grid(ix, blocks, fsplit, (d.P + GG - 1) / GG), (unsigned)vbytes);
                 BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2);
 #undef BOXATTN_FWD2
             } else {
@@ -424,8 +433,8 @@ int launch_fwd_grid(const ST *value, const int64_t *shapes, const int64_t *lsi, 
 #define BOXATTN_FWD2G(GG, VV)                                                                      \
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV, true>),   \
                        dim3(blocks, 1), dim3(256), 0, st, value, shapes, lsi, (const float *)nullptr, \
-                       attn, (const float *)nullptr, d.S, d.H, d.L, d.Lq, d.P, out, (ST *)nullptr, ix, \
-                       (unsigned)vbytes, gs);
+                       attn, (const float *)nullptr, d.S, d.H, d.L, d.Lq, d.P, out, (ST *)nullptr, \
+                       with_grid(ix, blocks, 1, 1), (unsigned)vbytes, gs);
     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2G);
 #undef BOXATTN_FWD2G
     return finish();
@@ -838,7 +847,7 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
                    dim3(wblocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
                    grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
-                   ix, (unsigned)vbytes);
+                   with_grid(ix, wblocks, split, tiles), (unsigned)vbytes);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
 #undef BOXATTN_PG2W
         } else {
@@ -851,7 +860,7 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
                                               false, true>),                                        \
                            dim3(blocks, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
                            grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp,        \
-                           grad_lv, ix, (unsigned)vbytes, *gs);
+                           grad_lv, with_grid(ix, blocks, 1, tiles), (unsigned)vbytes, *gs);
                     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2G);
 #undef BOXATTN_PG2G
                     return;
@@ -861,7 +870,7 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
                    dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
                    w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
-                   grad_lv, ix, (unsigned)vbytes);
+                   grad_lv, with_grid(ix, blocks, split, tiles), (unsigned)vbytes);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
 #undef BOXATTN_PG2
         }

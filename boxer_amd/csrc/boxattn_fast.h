@@ -38,6 +38,36 @@ __device__ __forceinline__ void load_levels(LevelTable &t, const int64_t *shapes
     __syncthreads();
 }
 
+// The same in two steps, so that a kernel can put its own first loads BETWEEN the request of the
+// level table and the barrier that publishes it: one global round trip at the start of a wave
+// instead of two in a row (s_memtime stamps in the point-gradient kernel: 6 600 of a wave's
+// 21 000 cycles passed before its loop started, tools/gpu_pg_trace.py).
+struct LevelRegs { int h, w, start; };
+__device__ __forceinline__ LevelRegs levels_request(const int64_t *shapes, const int64_t *lsi, int L)
+{
+    // unconditional loads from a clamped index: a load under a divergent branch makes the
+    // compiler wait for it at the join (s_waitcnt right there: the round trip this split avoids)
+    // ... and only the LOW dwords of the int64 entries (little endian; sizes < 2^31): loading the
+    // whole words leaves dead high halves whose registers the compiler hands out again at once
+    // -- with an s_waitcnt for the outstanding load in front of the first reuse
+    const int i = min((int)threadIdx.x, L - 1);
+    const int *sh32 = reinterpret_cast<const int *>(shapes), *ls32 = reinterpret_cast<const int *>(lsi);
+    LevelRegs r;
+    r.h = sh32[4 * i];
+    r.w = sh32[4 * i + 2];
+    r.start = ls32[2 * i];
+    return r;
+}
+__device__ __forceinline__ void levels_commit(LevelTable &t, const LevelRegs &r, int L)
+{
+    if ((int)threadIdx.x < L) {
+        t.h[threadIdx.x] = r.h;
+        t.w[threadIdx.x] = r.w;
+        t.start[threadIdx.x] = r.start;
+    }
+    __syncthreads();
+}
+
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a
 // private 4 MiB L2).  Consecutive queries sample neighbouring pixels, so give every XCD one
 // contiguous chunk of the query range instead of every 8th block.  Bijective for any grid.

@@ -35,6 +35,11 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOobOffset = 0x80000000u;     // >= any valid byte offset (tensor < 2 GiB)
+// The gather kernels are launched with 256 threads (4 waves).  A constant, not blockDim.x: the
+// block size lives in the dispatch packet, and reading it is a VECTOR global load plus
+// s_waitcnt vmcnt(0) at the top of every wave -- a full memory round trip before the first
+// useful load could be issued (s_memtime stamps: 6 200 of a wave's 21 000 cycles).
+constexpr unsigned kGatherWaves = 4;
 
 // Tuning switches (tools/build_variants.sh builds the alternatives side by side).
 #ifndef BOXATTN_TUNE_SCHED
@@ -247,6 +252,11 @@ struct GatherIdx {
     unsigned magic_lq;    // floor(2^32 / Lq)
     float rcp_p;          // 1.0f / P
     unsigned head_xcd;    // 1: workgroup b works on head b % 8 (H == 8), see pair_of_lane()
+    // launch geometry (with_grid() on the host, right before the launch).  Explicit arguments,
+    // not gridDim: the grid size lives in the hidden arguments (one more dependent scalar load
+    // at the top of every wave) and `tiles per workgroup` was an emulated integer division there
+    unsigned grid_x, grid_y;
+    unsigned tps;         // point tiles per workgroup row: ceil(tiles / grid_y)
 };
 
 // Which (query, head) pair a lane group works on.
@@ -261,13 +271,13 @@ __device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, int H, int
 {
     unsigned qh;
     if (ix.head_xcd) {
-        const unsigned tile = (blockIdx.x / 8) * (blockDim.x / kWave) + wv;
+        const unsigned tile = (blockIdx.x / 8) * kGatherWaves + wv;
         const unsigned bq = tile * PAIRS + j;
         active = bq < ix.n_qh / (unsigned)H;
         qh = bq * (unsigned)H + blockIdx.x % 8;
     } else {
-        const unsigned bid = xcd_chunked_block(blockIdx.x, gridDim.x);
-        qh = (bid * (blockDim.x / kWave) + wv) * PAIRS + j;
+        const unsigned bid = xcd_chunked_block(blockIdx.x, ix.grid_x);
+        qh = (bid * kGatherWaves + wv) * PAIRS + j;
         active = qh < ix.n_qh;
     }
     return active ? qh : ix.n_qh - 1;
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);   // channels of one piece
     __shared__ LevelTable lv;
     __shared__ u32x4_t geo_all[4][Tile::kSize];
-    load_levels(lv, shapes, lsi, L);
+    const LevelRegs lv_regs = levels_request(shapes, lsi, L);   // published below, after the first loads
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);   // this group's part of the tile
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                 xy4[k] = loc2[pt0 + k * G + slot];
                 a4[k] = w_sp[pt0 + k * G + slot];
             }
+            levels_commit(lv, lv_regs, L);
             // a rolled loop over the tiles (the registers rotate): unrolled, the scheduler pulls
             // the row loads of all four tiles to the front (299 VGPRs)
 #pragma unroll 1
@@ -420,6 +431,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
             float2 xy_n = make_float2(0.f, 0.f);
             if constexpr (!GRID) xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
             float a_n = w_sp[pt0 + min(slot, LP - 1)];
+            levels_commit(lv, lv_regs, L);
             for (int t0 = 0; t0 < LP; t0 += G) {
                 float2 xy = xy_n;
                 float a = a_n;
@@ -437,10 +449,11 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
             }
         }
     } else {
+        levels_commit(lv, lv_regs, L);
         ST *mk = mask + (size_t)bq * P * HC + (size_t)h * C + slot * LCH;
         // few queries x many points (decoder, 14x14 grids): gridDim.y workgroups share the
         // point tiles of a (query, head) pair; out is then accumulated with atomics
-        const int tiles = (P + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int tps = (int)ix.tps;                   // of (P + G - 1) / G tiles
         const int p_begin = (int)blockIdx.y * tps * G, p_end = min(P, p_begin + tps * G);
         for (int p0 = p_begin; p0 < p_end; p0 += G) {
             f32x2 macc[G][VEC / 2];
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     }
     if (active) {
         if constexpr (INST && std::is_same<ST, float>::value) {
-            if (gridDim.y > 1) {                   // split points: out was zero-filled by the host
+            if (ix.grid_y > 1) {                   // split points: out was zero-filled by the host
 #pragma unroll
                 for (int i = 0; i < VEC / 2; ++i) {
                     // channel of pair i: piece (2 i / 4), position (2 i % 4) inside it
@@ -551,9 +564,9 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     load_levels(lv, shapes, lsi, L);
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    unsigned qh = blockIdx.x * (blockDim.x / kWave) + wv;            // one pair per wave
+    unsigned qh = blockIdx.x * kGatherWaves + wv;            // one pair per wave
     if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
-        qh = ((blockIdx.x / 8) * (blockDim.x / kWave) + wv) * (unsigned)H + blockIdx.x % 8;
+        qh = ((blockIdx.x / 8) * kGatherWaves + wv) * (unsigned)H + blockIdx.x % 8;
     if (qh >= ix.n_qh) return;                                          // wave-uniform
     const int slot = lane % G, grp = lane / G;
     unsigned bq, hu, b, qu;
@@ -679,25 +692,41 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     // per-point results are collected per pair in LDS and written once, 16 / 32 contiguous bytes
     // per lane.  (Written tile by tile -- 4-byte and 8-byte pieces per lane, 16 points of a pair
     // in four separate instructions -- the kernel's HBM write traffic was twice its output.)
+#ifndef BOXATTN_TUNE_PG_TRACE
+#define BOXATTN_TUNE_PG_TRACE 0     // experiments only (overwrites grad_weight): s_memtime stamps of wave 0 of
+#endif                              // every workgroup: start, loop entry, each tile, end (tools/gpu_pg_trace.py)
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int ts_n = 0;
+    if constexpr (BOXATTN_TUNE_PG_TRACE) {
+        ts[ts_n++] = __builtin_amdgcn_s_memtime();
+        if (BOXATTN_TUNE_PG_TRACE == 2) {                     // finer stamps of the prologue instead of the tiles
+            asm volatile("" ::"s"(S), "s"(Lq));               // explicit kernel arguments have arrived
+            ts[2] = __builtin_amdgcn_s_memtime();
+        }
+    }
     constexpr int kBufLP = 16;
     constexpr bool kCanBuffer = !INST && (G == 4 || G == 8);
     __shared__ float res_all[kCanBuffer ? 4 * PAIRS * kBufLP * 3 : 1];
-    load_levels(lv, shapes, lsi, L);
+    const LevelRegs lv_regs = levels_request(shapes, lsi, L);   // published below, after the first loads
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);
     bool active;
     unsigned qh;
     if constexpr (WP) {
-        qh = blockIdx.x * (blockDim.x / kWave) + wv;                      // one pair per wave
+        qh = blockIdx.x * kGatherWaves + wv;                      // one pair per wave
         if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
-            qh = ((blockIdx.x / 8) * (blockDim.x / kWave) + wv) * (unsigned)H + blockIdx.x % 8;
+            qh = ((blockIdx.x / 8) * kGatherWaves + wv) * (unsigned)H + blockIdx.x % 8;
         active = qh < ix.n_qh;
         qh = active ? qh : ix.n_qh - 1;
     } else {
         qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
     }
     const int slot = lane % G;
+    if constexpr (BOXATTN_TUNE_PG_TRACE == 2) {
+        asm volatile("" ::"v"(qh));                           // the pair index exists (grid size read)
+        ts[3] = __builtin_amdgcn_s_memtime();
+    }
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
     divmod_magic(bq, (unsigned)Lq, ix.magic_lq, b, qu);
@@ -716,7 +745,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
 
     // gridDim.y workgroups share the point tiles of a pair (few queries x many points).
     // t_step: distance between two tiles of a lane group (WP: the groups interleave)
-    const int tiles = (LP + G - 1) / G, tps = (tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int tps = (int)ix.tps;                       // of (LP + G - 1) / G tiles
     const int t_first = (int)blockIdx.y * tps * G, t_end = min(LP, t_first + tps * G);
     const int t_begin = t_first + (WP ? (lane / G) * G : 0);
     constexpr int t_step = WP ? PAIRS * G : G;
@@ -726,22 +755,33 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     // BoxeR's shape (L P = 4 G): all four tiles' locations / weights are requested up front,
     // one HBM round trip per wave instead of one per tile (see fwd2_kernel)
     constexpr bool kCanPre = kGatherPreload && !INST && !WP && G == 4;
-    const bool pre = kCanPre && gridDim.y == 1 && LP == kPreTiles * G;
+    const bool pre = kCanPre && ix.grid_y == 1 && LP == kPreTiles * G;
     float2 xyq[kCanPre ? kPreTiles - 1 : 1];
     float asq[kCanPre ? kPreTiles - 1 : 1];
 #pragma unroll
     for (int k = 0; k < (kCanPre ? kPreTiles - 1 : 1); ++k) {
         xyq[k] = make_float2(0.f, 0.f);
         asq[k] = 0.f;
-        if (pre) {
-            xyq[k] = loc2[pt0 + (k + 1) * G + slot];
-            asq[k] = w_sp[pt0 + (k + 1) * G + slot];
+        if constexpr (kCanPre) {
+            // unconditional, from a clamped index (other shapes just do not use them): under
+            // `if (pre)` the compiler merges the loaded registers with the zeros at the join and
+            // WAITS for the load there -- the round trip this is meant to remove
+            const int pq = min((k + 1) * G + slot, LP - 1);
+            xyq[k] = loc2[pt0 + pq];
+            asq[k] = w_sp[pt0 + pq];
         }
     }
-    const bool buffered = kCanBuffer && !WP && gridDim.y == 1 && (LP == 16 || LP == 8) &&
+    if constexpr (BOXATTN_TUNE_PG_TRACE) {
+        __builtin_amdgcn_sched_barrier(0);
+        ts[6] = __builtin_amdgcn_s_memtime();                 // first loads issued, before the barrier
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    levels_commit(lv, lv_regs, L);
+    const bool buffered = kCanBuffer && !WP && ix.grid_y == 1 && (LP == 16 || LP == 8) &&
                           (((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0 ||
                            GRID);      // (GRID: the host has checked; grad_loc is not used)
     float *res = res_all + (kCanBuffer ? (wv * PAIRS + lane / G) * (kBufLP * 3) : 0);
+    if constexpr (BOXATTN_TUNE_PG_TRACE) ts[ts_n++] = __builtin_amdgcn_s_memtime();
     // (wave-uniform trip count: with WP the groups whose tile lies past the end idle)
     for (int tu = t_first, t0 = t_begin; tu < t_end; tu += t_step, t0 += t_step) {
         // ---- step A (the lane keeps its point's geometry in registers for the finish)
@@ -792,6 +832,19 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                 u32x4_t off;
                 if constexpr (UseQuadDpp<G>::value) off = quad_bcast(myoff, tb + u);
                 else off = geo[tb + u];
+#ifndef BOXATTN_TUNE_PG_ABLATE
+#define BOXATTN_TUNE_PG_ABLATE 0    // timing experiments only (wrong results): 2 = every row load hits
+#endif                              // the first 4 KiB of value (L1 hits), 3 = no row loads
+                if constexpr (BOXATTN_TUNE_PG_ABLATE == 2) {
+                    off.x &= 0xfc0u; off.y &= 0xfc0u; off.z &= 0xfc0u; off.w &= 0xfc0u;
+                }
+                if constexpr (BOXATTN_TUNE_PG_ABLATE == 3 && !INST) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < RowT::NW; ++i) v[u][k].w[i] = off[k] + i;
+                    continue;
+                }
                 row_load<ST, VEC, PSB>(rs, off.x + lane_off, v[u][0]);
                 row_load<ST, VEC, PSB>(rs, off.y + lane_off, v[u][1]);
                 row_load<ST, VEC, PSB>(rs, off.z + lane_off, v[u][2]);
@@ -821,6 +874,10 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                     m1 = mine ? b1 : m1; m2 = mine ? b2 : m2; m3 = mine ? b3 : m3; m4 = mine ? b4 : m4;
                 }
             }
+        }
+        if constexpr (BOXATTN_TUNE_PG_TRACE) {
+            asm volatile("" ::"v"(s1), "v"(s4));              // after the tile's sums exist
+            if (BOXATTN_TUNE_PG_TRACE == 1 && ts_n < 7) ts[ts_n++] = __builtin_amdgcn_s_memtime();
         }
         // ---- finish: lane (pair, slot) owns point t0 + slot
         if (active && have) {
@@ -892,6 +949,15 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
                 *gsp = res[p0];
                 if constexpr (!GRID) *reinterpret_cast<float2 *>(gl) = make_float2(r[0], r[1]);
             }
+        }
+    }
+    if constexpr (BOXATTN_TUNE_PG_TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
+        ts[7] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && wv == 0 && active) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) grad_sp[pt0 + k] = (float)(unsigned)(ts[k] - ts[0]);
+            grad_sp[pt0] = (float)(unsigned)(ts[0] & 0xffffffu);      // start time (low bits): launch order
         }
     }
 }
