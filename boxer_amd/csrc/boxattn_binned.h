@@ -352,6 +352,12 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
             for (int w = 0; w < wv; ++w) pre += wsum[i][w];
             ex[i] = pre + inc[i] - v[i];
         }
+        // Items are listed HEAVIEST FIRST (the coarse levels' chunked blocks are the last ones
+        // in block order): item i of the list is the (total - 1 - i)-th in block order.  Stored that
+        // way round, an accumulate worker's first item is items[worker] -- a load it can issue at
+        // once, next to the one for the item count, instead of after it.
+        int tot_items = carry[1];                  // (one pass: the host sends bigger maps to the segment kernels)
+        for (int w = 0; w < kScanThreads / 64; ++w) tot_items += wsum[1][w];
         if (live) {
             offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
             int level = 0;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
                 if (l == level) lv = plan.lv[l];
             const int geo = (int)pack_block_geo(lv, level, k);
             for (int j = 0; j < nch; ++j)
-                items[(size_t)s * plan.item_cap + ex[1] + j] =     // record range inside the slice
+                items[(size_t)s * plan.item_cap + (tot_items - 1 - (ex[1] + j))] =   // record range inside the slice
                     make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
                               nch > 1 ? ex[2] + j : -1);          // .w = partial slot or -1
             if (nch > 1)
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_emit_kernel(int *__rest
             if (l == level) lv = plan.lv[l];
         const int geo = (int)pack_block_geo(lv, level, k);
         for (int j = 0; j < nch; ++j)
-            items[(size_t)s * plan.item_cap + ex[1] + j] =
+            items[(size_t)s * plan.item_cap + (all[1] - 1 - (ex[1] + j))] =      // heaviest first
                 make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
                           nch > 1 ? ex[2] + j : -1);
         if (nch > 1) combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
@@ -595,13 +601,13 @@ void binned_accumulate_kernel(
     // in one cache line every dequeue of the chip serialised on that line -- 13 k atomics =
     // 160 us --, and with padded heads the dequeue round trip still cost 10 %.)
     const int4 *my_items = items + (size_t)s * plan.item_cap;
-    int4 item_n = worker < n_it ? my_items[n_it - 1 - worker] : make_int4(0, 0, 0, 0);
+    int4 item_n = my_items[min(worker, plan.item_cap - 1)];      // (list is heaviest first)
     for (int it = worker; it < n_it; it += workers) {
         // coarse levels sit at the end of the list and carry the long chunked items: take
         // them first so the tail of the kernel is made of short items (the next item of this
         // workgroup is requested while it works on the current one)
         const int4 item = item_n;
-        if (it + workers < n_it) item_n = my_items[n_it - 1 - (it + workers)];
+        item_n = my_items[min(it + workers, plan.item_cap - 1)];
         const BlockGeo bg = unpack_block_geo((unsigned)item.x);
         BinLevel lv = plan.lv[0];                    // select, no dynamic indexing of kernel args
 #pragma unroll

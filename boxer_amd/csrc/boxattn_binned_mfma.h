@@ -115,10 +115,10 @@ __global__ __launch_bounds__(64) void binned_accumulate_mfma_kernel(
     // (a workgroup with several items -- big, mostly empty maps -- has its next item in flight while
     // it works on the current one: an empty block is otherwise one dependent load per 2 KB stored)
     const int4 *my_items = items + (size_t)s * plan.item_cap;
-    int4 item_n = worker < n_it ? my_items[n_it - 1 - worker] : make_int4(0, 0, 0, 0);
+    int4 item_n = my_items[min(worker, plan.item_cap - 1)];      // (list is heaviest first)
     for (int it = worker; it < n_it; it += workers) {
         const int4 item = item_n;                                               // heaviest first
-        if (it + workers < n_it) item_n = my_items[n_it - 1 - (it + workers)];
+        item_n = my_items[min(it + workers, plan.item_cap - 1)];
         const BlockGeo bg = unpack_block_geo((unsigned)item.x);
         BinLevel lv = plan.lv[0];
 #pragma unroll
