@@ -185,15 +185,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     const int n_pts = n_q * LP;
     int *mypart = part + ((size_t)s * n_wg + wg) * plan.nblk;
     __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane below (no select chains)
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
-    }
-    const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in bin_scan_a_kernel
-    const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
-    for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads)
-        hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
-    __syncthreads();
 
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     static_assert(PT == 1 || PT == 4, "points per thread and step");
@@ -204,10 +195,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
     const float rcp_lpg = 1.0f / (float)LPG, rcp_p = 1.0f / (float)P;
     int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
     (void)n_pts;
-    for (int g0 = threadIdx.x; g0 < n_grp; g0 += kBinThreads * U) {
-        float2 xy[U][PT];
-        float wv[U][PT];
-        int lp0[U], ql[U];
+    // one step's points of this thread (clamped: every thread loads from valid addresses)
+    float2 xy[U][PT];
+    float wv[U][PT];
+    int lp0[U], ql[U];
+    auto load_step = [&](int g0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int g = min(g0 + u * kBinThreads, n_grp - 1);
@@ -233,6 +225,23 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
                 for (int k = 0; k < PT; ++k) wv[u][k] = 0.f;
             }
         }
+    };
+    // The first step's loads go out BEFORE the level table / histogram set-up and its barrier: the
+    // set-up's own round trip (the fill pass reads three tables per block) then runs under theirs
+    // instead of in front of it (a workgroup usually has ONE step: a serial chain of two round trips).
+    if (n_grp > 0) load_step((int)threadIdx.x);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
+    }
+    const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in bin_scan_a_kernel
+    const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
+    for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads)
+        hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
+    __syncthreads();
+
+    for (int g0 = threadIdx.x; g0 < n_grp; g0 += kBinThreads * U) {
+        if (g0 != (int)threadIdx.x) load_step(g0);           // later steps (big workgroups only)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g0 + u * kBinThreads >= n_grp) break;
