@@ -252,6 +252,41 @@ def test_instance_backward_algorithms(cfg, dtype, variant):
     close(glw, want[3], torch.float32, "grad_level")
 
 
+@pytest.mark.parametrize("chunk", [64, 192, 1024, 4096])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_binned_backward_records_per_item(dtype, chunk):
+    """boxattn_set_option(10): the records per work item only change how a bin is cut into work
+    items (and how many partial tiles the combine pass sums), never the result -- heavy bins
+    (3 000 queries on a 16 x 24 map) and a multi-level map with a one-block level."""
+    from boxer_amd import _lib
+    for cfg in (FAST_CFGS[-1], ([(25, 25), (13, 13), (7, 5), (1, 3), (2, 1)], 1, 2, 32, 700, 4)):
+        g = _seeded(*cfg, seed=31, lo=-0.2, hi=1.2)
+        want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                    g["grad_out"])
+        old = _lib.set_option("bin_chunk", chunk)
+        try:
+            out, gv, gl, ga = run_box(g, dtype, "binned")
+        finally:
+            _lib.set_option("bin_chunk", old)
+        close(gv, want[0], dtype, "grad_value")
+        close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
+        close(ga, want[2], torch.float32, "grad_attn")
+
+
+def test_block_scan_over_several_workgroups():
+    """More than 1 024 blocks per (image, head) slice (here a 200 x 180 map: 25 x 45 = 1 125): the
+    block scan runs as bin_scan_seg_kernel + bin_scan_emit_kernel; few queries, so most blocks are
+    empty and have to come back as zeros."""
+    g = _seeded([(200, 180), (20, 18)], 1, 2, 32, 150, 4, seed=32)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    for dtype in (torch.float32, torch.bfloat16):
+        out, gv, gl, ga = run_box(g, dtype, "binned")
+        close(gv, want[0], dtype, "grad_value")
+        close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
+        close(ga, want[2], torch.float32, "grad_attn")
+
+
 def test_binned_backward_clustered_points():
     """All sample points of a head on one pixel: one bin gets every record (many chunks),
     all other bins are empty."""
