@@ -174,3 +174,24 @@ def test_reference_style_function_on_the_compiled_module(compiled):
     attn = torch.rand(1, 2, 2, 2, 2, device="cuda", dtype=torch.double) + 1e-5
     attn = (attn / attn.sum((-1, -2), keepdim=True)).requires_grad_()
     assert gradcheck(RefStyleBoxAttn.apply, (value, shapes, lsi, loc, attn, 2))
+
+
+@pytest.mark.gpu
+def test_runs_on_the_current_stream(compiled):
+    """The module launches on torch's CURRENT stream of the tensors' device (c10's stream guard):
+    work queued on a side stream behind a long-running kernel must see that kernel's result."""
+    g = golden_io.load("G6_box_ml")
+    value, loc, attn = (_dev(g[k], torch.float32) for k in ("value", "loc", "attn"))
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    want = compiled.box_attn_forward(value, shapes, lsi, loc, attn, 64)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    scratch = torch.zeros_like(value)
+    with torch.cuda.stream(side):
+        big = torch.randn(4096, 4096, device="cuda")
+        for _ in range(20):                       # keeps the side stream busy for a while
+            big = big @ big * 1e-4
+        scratch.copy_(value)                      # queued behind the matmuls, on the side stream
+        out = compiled.box_attn_forward(scratch, shapes, lsi, loc, attn, 64)
+    side.synchronize()
+    assert torch.equal(out, want)
