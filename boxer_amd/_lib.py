@@ -15,8 +15,12 @@ LIB_PATH = os.path.join(_PKG, LIB_NAME)
 INCLUDE_DIR = os.path.join(os.path.dirname(_PKG), "include")
 SOURCES = ["boxattn_capi.hip"]
 HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
+# -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments (its pointers) arrive in
+# SGPRs with the wave instead of through scalar loads at its top (gfx94x / gfx950); every wave of
+# these kernels is short, and their prologues are a measurable part of them
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-shared", "-Wall", "-Wno-pass-failed"]
+               "-shared", "-Wall", "-Wno-pass-failed",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 _lib = None
 
