@@ -273,11 +273,15 @@ def test_binned_backward_records_per_item(dtype, chunk):
         close(ga, want[2], torch.float32, "grad_attn")
 
 
-def test_block_scan_over_several_workgroups():
-    """More than 1 024 blocks per (image, head) slice (here a 200 x 180 map: 25 x 45 = 1 125): the
-    block scan runs as bin_scan_seg_kernel + bin_scan_emit_kernel; few queries, so most blocks are
-    empty and have to come back as zeros."""
-    g = _seeded([(200, 180), (20, 18)], 1, 2, 32, 150, 4, seed=32)
+@pytest.mark.parametrize("levels", [[(128, 256)],               # 32 x 32 = 1 024 blocks: still one workgroup
+                                    [(128, 264)],               # 1 056: just over
+                                    [(128, 512)],               # 2 048: exactly two segments
+                                    [(200, 180), (20, 18)]],    # 1 125 + 15, two levels
+                         ids=["1024", "1056", "2048", "2lv"])
+def test_block_scan_over_several_workgroups(levels):
+    """More than 1 024 blocks per (image, head) slice: the block scan runs as bin_scan_seg_kernel +
+    bin_scan_emit_kernel; few queries, so most blocks are empty and have to come back as zeros."""
+    g = _seeded(levels, 1, 2, 32, 150, 4, seed=32)
     want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
                                 g["grad_out"])
     for dtype in (torch.float32, torch.bfloat16):
