@@ -311,11 +311,15 @@ __global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part,
 }
 
 constexpr int kScanThreads = 1024;     // one workgroup per slice walks the blocks 1024 at a time
+// fuse_wg > 0: kernel A's work is done here as well (every thread walks the fuse_wg workgroup
+// counts of its block itself): one launch less -- what the decoder shapes, whose step is a chain
+// of short kernels, are made of -- at the price of fuse_wg loads per thread instead of 16 + 8.
 __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict__ subtot,
                                                        int *__restrict__ offsets,
                                                        int4 *__restrict__ items,
                                                        int4 *__restrict__ combos,
-                                                       int *__restrict__ n_items, BinPlan plan)
+                                                       int *__restrict__ n_items, BinPlan plan,
+                                                       int *__restrict__ part, int fuse_wg)
 {
     // four running sums over the blocks: records, items, partial slots, chunked blocks
     __shared__ int wsum[4][kScanThreads / 64];
@@ -327,7 +331,21 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
         const int k = k0 + threadIdx.x;
         const bool live = k < plan.nblk;
         int c = 0;
-        if (live) {                                // sub-range totals -> sub-range first slots
+        if (live && fuse_wg > 0) {                 // workgroup counts -> first slots, both levels
+            const int wps = (fuse_wg + kScanSub - 1) / kScanSub;
+            int *sp = part + (size_t)s * fuse_wg * plan.nblk + k;
+            for (int u = 0; u < kScanSub; ++u) {
+                subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;
+                int in_sub = 0;
+                const int w_hi = min(fuse_wg, (u + 1) * wps);
+                for (int w = u * wps; w < w_hi; ++w) {
+                    const int t = sp[(size_t)w * plan.nblk];
+                    sp[(size_t)w * plan.nblk] = in_sub;
+                    in_sub += t;
+                }
+                c += in_sub;
+            }
+        } else if (live) {                         // sub-range totals -> sub-range first slots
             int t[kScanSub];
 #pragma unroll
             for (int u = 0; u < kScanSub; ++u)

@@ -783,9 +783,15 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
                                w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
     } while (0)
     BOXATTN_BIN(false);
-    hipLaunchKernelGGL(bin_scan_a_kernel,
-                       dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
-                       part, w.n_wg, subtot, plan);
+#ifndef BOXATTN_TUNE_SCAN_FUSE_WG
+#define BOXATTN_TUNE_SCAN_FUSE_WG 48   // up to this many bin workgroups per slice the block scan does kernel A's work too
+                                       // (38 workgroups, the 300-query decoders: C3'' fp32 68 -> 61 us; 64, C2: binning 49 -> 61 us)
+#endif
+    const bool fuse_a = plan.nblk <= kScanThreads && w.n_wg <= BOXATTN_TUNE_SCAN_FUSE_WG;
+    if (!fuse_a)
+        hipLaunchKernelGGL(bin_scan_a_kernel,
+                           dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
+                           part, w.n_wg, subtot, plan);
     if (plan.nblk > kScanThreads) {                  // big maps: the block scan over several CUs
         const int nseg = (plan.nblk + kScanThreads - 1) / kScanThreads;
         int4 *tmp = (int4 *)(ws + w.scan_tmp), *segtot = tmp + (size_t)ns * plan.nblk;
@@ -795,7 +801,7 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
                            tmp, segtot, items, combos, n_items, plan);
     } else {
         hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets,
-                           items, combos, n_items, plan);
+                           items, combos, n_items, plan, part, fuse_a ? w.n_wg : 0);
     }
     BOXATTN_BIN(true);
 #undef BOXATTN_BIN
