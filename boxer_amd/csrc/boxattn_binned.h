@@ -892,24 +892,38 @@ void binned_accumulate_kernel(
 // 6: sum the partial tiles of the blocks that were cut into chunks.  grid = (workers, slices),
 //    one wavefront each, looping over the slice's chunked blocks (only the coarse levels).
 // ---------------------------------------------------------------------------------------
+// What the combine step needs of the plan (small enough to ride along in another kernel's arguments).
+struct CombinePlan {
+    int nblk, pslot_cap, n_slices;
+    int start[kMaxBinLevels], W[kMaxBinLevels];
+};
+inline CombinePlan combine_plan(const BinPlan &p)
+{
+    CombinePlan c;
+    c.nblk = p.nblk; c.pslot_cap = p.pslot_cap; c.n_slices = p.n_slices;
+    for (int k = 0; k < kMaxBinLevels; ++k) { c.start[k] = p.lv[k].start; c.W[k] = p.lv[k].W; }
+    return c;
+}
+// One wavefront (lane = threadIdx & 63) as worker `worker` of `n_workers` of slice s.
 template <typename ST, int C>
-__global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__restrict__ combos,
-                                                              const int *__restrict__ n_items,
-                                                              const float *__restrict__ partials,
-                                                              BinPlan plan, int S, int H,
-                                                              ST *__restrict__ grad_value)
+__device__ __forceinline__ void combine_partials_body(const int4 *__restrict__ combos,
+                                                      const int *__restrict__ n_items,
+                                                      const float *__restrict__ partials,
+                                                      const CombinePlan &plan, int S, int H,
+                                                      ST *__restrict__ grad_value, int s, int worker,
+                                                      int n_workers, int lane)
 {
     constexpr int BW = 8, PB = 32, CH = C / 2, EPL = 16 / (int)sizeof(ST);
-    const int s = blockIdx.y, b = s / H, h = s % H;
+    const int b = s / H, h = s % H;
     const int n_comb = n_items[2 * s + 1];
-    const int mypix = threadIdx.x >> 1, half = threadIdx.x & 1;
-    for (int ci = blockIdx.x; ci < n_comb; ci += gridDim.x) {
+    const int mypix = lane >> 1, half = lane & 1;
+    for (int ci = worker; ci < n_comb; ci += n_workers) {
         const int4 cb = combos[(size_t)s * plan.nblk + ci];          // {block geometry, first slot, nch}
         const BlockGeo bg = unpack_block_geo((unsigned)cb.x);
-        BinLevel lv = plan.lv[0];
+        int lv_start = plan.start[0], lv_W = plan.W[0];
 #pragma unroll
         for (int k = 1; k < kMaxBinLevels; ++k)
-            if (k == bg.level) lv = plan.lv[k];
+            if (k == bg.level) { lv_start = plan.start[k]; lv_W = plan.W[k]; }
         const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
         if (mypix / BW >= bh || mypix % BW >= bw) continue;
         const int yy = oy + mypix / BW, xx = ox + mypix % BW;
@@ -938,7 +952,7 @@ __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__rest
                 }
             }
         }
-        ST *dst = grad_value + (((size_t)b * S + lv.start + (size_t)yy * lv.W + xx) * H + h) * C +
+        ST *dst = grad_value + (((size_t)b * S + lv_start + (size_t)yy * lv_W + xx) * H + h) * C +
                   half * CH;
 #pragma unroll
         for (int c = 0; c < CH; c += EPL) {
@@ -948,6 +962,17 @@ __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__rest
             VecIO<ST, EPL>::st(dst + c, t);
         }
     }
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__restrict__ combos,
+                                                              const int *__restrict__ n_items,
+                                                              const float *__restrict__ partials,
+                                                              CombinePlan plan, int S, int H,
+                                                              ST *__restrict__ grad_value)
+{
+    combine_partials_body<ST, C>(combos, n_items, partials, plan, S, H, grad_value, (int)blockIdx.y,
+                                 (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
 
 }  // namespace boxattn

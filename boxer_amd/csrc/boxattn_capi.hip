@@ -827,7 +827,7 @@ template <typename ST, int G, bool INST>
 void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                       const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st,
-                      const GridSrc *gs = nullptr)
+                      const GridSrc *gs = nullptr, const CombineTail *ct = nullptr)
 {
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
     const size_t n_qh = d.n_qh();
@@ -843,6 +843,9 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
 #define BOXATTN_TUNE_PG_WAVE_PER_PAIR 1
 #endif
         const int tiles = (d.L * d.P + cfg.G - 1) / cfg.G;
+        // the combine step's workers as extra workgroups of this launch (4 single-wave workers each)
+        const CombineTail tail = ct ? *ct : CombineTail{};
+        const int tail_blocks = tail.workers > 0 ? (tail.workers * tail.plan.n_slices + 3) / 4 : 0;
         const bool wpp = BOXATTN_TUNE_PG_WAVE_PER_PAIR && INST && g_variant != 5 &&
                          blocks < 1024 && tiles >= kWave / cfg.G;
         if (wpp) {
@@ -851,9 +854,9 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
             const int split = point_split(wblocks, tiles / (kWave / cfg.G));
 #define BOXATTN_PG2W(GG, VV)                                                                         \
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
-                   dim3(wblocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
+                   dim3(wblocks + tail_blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
                    grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
-                   with_grid(ix, wblocks, split, tiles), (unsigned)vbytes);
+                   with_grid(ix, wblocks, split, tiles), (unsigned)vbytes, GridSrc{}, tail);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
 #undef BOXATTN_PG2W
         } else {
@@ -864,9 +867,9 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
     if constexpr (GG == 4 || GG == 8)                                                               \
         hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV,   \
                                               false, true>),                                        \
-                           dim3(blocks, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
+                           dim3(blocks + tail_blocks, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,  \
                            grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp,        \
-                           grad_lv, with_grid(ix, blocks, 1, tiles), (unsigned)vbytes, *gs);
+                           grad_lv, with_grid(ix, blocks, 1, tiles), (unsigned)vbytes, *gs, tail);
                     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2G);
 #undef BOXATTN_PG2G
                     return;
@@ -874,9 +877,9 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
             }
 #define BOXATTN_PG2(GG, VV)                                                                   \
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
-                   dim3(blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
+                   dim3(blocks + tail_blocks, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,  \
                    w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
-                   grad_lv, with_grid(ix, blocks, split, tiles), (unsigned)vbytes);
+                   grad_lv, with_grid(ix, blocks, split, tiles), (unsigned)vbytes, GridSrc{}, tail);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
 #undef BOXATTN_PG2
         }
@@ -886,6 +889,10 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
                            0, st, value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask,
                            d.S, d.H, d.L, d.Lq, d.P, (float *)nullptr, grad_loc, grad_sp, grad_lv,
                            n_qh);
+        if (ct && ct->workers > 0)               // this kernel carries no tail: the combine step on its own
+            hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(ct->workers, ct->plan.n_slices),
+                               dim3(64), 0, st, ct->combos, ct->n_items, ct->partials, ct->plan, d.S,
+                               d.H, static_cast<ST *>(ct->grad_value));
     }
 }
 
@@ -908,8 +915,17 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     SideStream side(st, side_stream_worth<ST>(d));
     const bool use_mfma = mfma_accumulate<ST, INST>(d), wide = wide_records<ST, INST>(d);
     if (!plan_ready) launch_binning(wide, !use_mfma, loc, w_sp, d, plan, w, ws, st);
-    launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
-                                  grad_sp, grad_lv, side.stream(), gs);
+    // On one stream the point gradients go LAST and carry the combine step's workers as extra
+    // workgroups (CombineTail): one launch less, 5-7 us of every step.  With the helper stream
+    // (variant 6) they run next to the binning / accumulate kernels and the combine step keeps
+    // its own launch.
+#ifndef BOXATTN_TUNE_COMBINE_TAIL
+#define BOXATTN_TUNE_COMBINE_TAIL 1
+#endif
+    const bool tail = BOXATTN_TUNE_COMBINE_TAIL && side.stream() == st;
+    if (!tail)
+        launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d,
+                                      grad_loc, grad_sp, grad_lv, side.stream(), gs);
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
     // real count lives on the device, surplus workgroups exit at once); the hardware dispatcher
     // hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
@@ -961,10 +977,14 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
             }
         }
     }
-    {
+    if (tail) {
+        CombineTail ct{combos, n_items, partials, grad_value, combine_plan(plan), 64};
+        launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d,
+                                      grad_loc, grad_sp, grad_lv, st, gs, &ct);
+    } else {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
         hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
-                           n_items, partials, plan, d.S, d.H, grad_value);
+                           n_items, partials, combine_plan(plan), d.S, d.H, grad_value);
     }
     side.join();
     return finish();

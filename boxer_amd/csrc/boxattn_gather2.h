@@ -28,6 +28,7 @@
 #include "boxattn_device.h"
 #include "boxattn_fast.h"
 #include "boxattn_grid.h"
+#include "boxattn_binned.h"
 
 namespace boxattn {
 
@@ -660,6 +661,21 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     if (grp == 0) row_store<ST, VEC, PSB>(out + (size_t)qh * C + slot * LCH, acc);
 }
 
+// The combine step of the binned backward (sum the partial tiles of the chunked blocks,
+// boxattn_binned.h step 6) riding along in the point-gradient launch: `workers` single-wave workers
+// per slice are appended to the grid as extra workgroups.  The two have nothing to do with each
+// other except that the point gradients are the LAST kernel of the backward once they are launched
+// after the accumulate kernel -- and a launch of its own for a few hundred waves of work is 5-7 us
+// of every step (a tenth of a decoder-shaped one).
+struct CombineTail {
+    const int4 *combos;
+    const int *n_items;
+    const float *partials;
+    void *grad_value;
+    CombinePlan plan;
+    int workers;          // per slice; 0: no combine work in this launch
+};
+
 // ---------------------------------------------------------------------------------------
 // backward, point gradients only (grad_loc, grad_weight[s]); grad_value is boxattn_binned.h
 // ---------------------------------------------------------------------------------------
@@ -678,10 +694,22 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const float *__restrict__ w_sp, const float *__restrict__ w_lv,
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask, int S, int H, int L,
     int Lq, int P, float *__restrict__ grad_loc, float *__restrict__ grad_sp,
-    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, GridSrc gs = GridSrc{})
+    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, GridSrc gs = GridSrc{},
+    CombineTail ct = CombineTail{})
 {
     static_assert(!GRID || (!INST && !WP && (G == 4 || G == 8)), "needs the buffered epilogue");
     constexpr int C = VEC * G, PAIRS = kWave / G;
+    if (ct.workers > 0 && blockIdx.x >= ix.grid_x) {          // the appended combine workgroups
+        if (blockIdx.y == 0) {
+            const int w = (int)((blockIdx.x - ix.grid_x) * kGatherWaves + threadIdx.x / kWave);
+            const int s = w / ct.workers;
+            if (s < ct.plan.n_slices)
+                combine_partials_body<ST, C>(ct.combos, ct.n_items, ct.partials, ct.plan, S, H,
+                                             static_cast<ST *>(ct.grad_value), s, w % ct.workers,
+                                             ct.workers, (int)(threadIdx.x & (kWave - 1)));
+        }
+        return;
+    }
     typedef GeoTile<G, 1> Tile;                      // offsets only: the weights stay with lane t
     typedef Row<ST, VEC> RowT;
     constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;    // bytes between a lane's pieces
