@@ -31,8 +31,10 @@ def _stale():
     if not os.path.exists(EXT_PATH):
         return True
     built = os.path.getmtime(EXT_PATH)
-    deps = [SOURCE, os.path.join(_lib.INCLUDE_DIR, "boxattn.h")]
-    return any(os.path.getmtime(d) > built for d in deps)
+    # the header (ABI changes), the source, and the library the module links against; a dependency
+    # that is not there (installed package without the sources) does not make the module stale
+    deps = [SOURCE, os.path.join(_lib.INCLUDE_DIR, "boxattn.h"), _lib.LIB_PATH]
+    return any(os.path.getmtime(d) > built for d in deps if os.path.exists(d))
 
 
 def _compile_command():
@@ -82,5 +84,8 @@ def load():
     spec = importlib.util.spec_from_file_location(MODULE_NAME, EXT_PATH, loader=loader)
     mod = importlib.util.module_from_spec(spec)
     loader.exec_module(mod)
+    if _lib.load().boxattn_abi_version() != _lib.ABI_VERSION:
+        raise RuntimeError("%s was built against another ABI of %s: rebuild (python setup.py "
+                           "build_ext --inplace)" % (MODULE_NAME, _lib.LIB_NAME))
     sys.modules[MODULE_NAME] = mod
     return mod

@@ -12,7 +12,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_NAME = "libboxattn_hip.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
+# the C-ABI header: the source checkout's include/ when there is one, else the copy a non-editable
+# install ships inside the package (setup.py: package_data "include/*.h")
 INCLUDE_DIR = os.path.join(os.path.dirname(_PKG), "include")
+if not os.path.exists(os.path.join(INCLUDE_DIR, "boxattn.h")):
+    INCLUDE_DIR = os.path.join(_PKG, "include")
 SOURCES = ["boxattn_capi.hip"]
 HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments (its pointers) arrive in
@@ -93,7 +97,7 @@ def needs_build():
         return True
     built = os.path.getmtime(LIB_PATH)
     srcs = [os.path.join(_CSRC, f) for f in SOURCES + HEADERS]
-    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "boxattn.h"))
+    srcs.append(os.path.join(INCLUDE_DIR, "boxattn.h"))
     return any(os.path.getmtime(s) > built for s in srcs if os.path.exists(s))
 
 

@@ -632,8 +632,11 @@ template <typename ST, bool INST> inline bool wide_records(const Dims &d)
 // whenever a flavour of that type may write them
 inline bool wide_workspace(bool is_bf16, const Dims &d)
 {
+    // float32: only the opt-in matrix-core flavour (variant 11) writes wide records; a call whose
+    // variant changed after the size query finds the workspace too small and takes the fallback
     return is_bf16 ? BOXATTN_TUNE_ACC_MFMA != 0
-                   : (BOXATTN_TUNE_WIDE_F32 != 0 || (BOXATTN_TUNE_ACC_MFMA != 0 && d.C == 32));
+                   : (BOXATTN_TUNE_WIDE_F32 != 0 ||
+                      (BOXATTN_TUNE_ACC_MFMA != 0 && d.C == 32 && g_variant == 11));
 }
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
@@ -1150,6 +1153,9 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         w = ws_layout(d, plan, wide_workspace(kBf16, d));
         binned = workspace_bytes >= w.total;
     }
+    // the boxes-in entry points never take the atomic fallback (its grad_loc slot is aliased to
+    // grad_offsets there, a smaller buffer): an undersized workspace is "not eligible"
+    if (gs && !binned) return kNotEligible;
     if (!binned) {
         // (a plan the forward built is simply not used when the backward's own checks -- e.g. an
         // unaligned grad_out view -- rule the binned path out: the atomic path needs no plan)

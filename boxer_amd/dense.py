@@ -32,6 +32,29 @@ def _acc_dtype(dtype):
     return torch.float32 if dtype in (torch.bfloat16, torch.float16) else dtype
 
 
+_BMM_OUT_DTYPE = None     # does torch.bmm take out_dtype on this build / device? (probed once)
+
+
+def _bmm_acc(a, b, acc):
+    """Batched product whose partial products leave in ``acc`` (float32 for bf16 / fp16 inputs): one
+    rounding per dW element instead of one bf16 rounding per row chunk.  Builds whose ``bmm`` has no
+    ``out_dtype`` fall back to storage-type partials: each of the n_chunk partials then carries a
+    2^-9 relative rounding, i.e. |err(dW)| <= 2^-9 * sum_chunks |partial| (documented bound)."""
+    global _BMM_OUT_DTYPE
+    if a.dtype == acc:
+        return torch.bmm(a, b)
+    if _BMM_OUT_DTYPE is not False:
+        try:
+            out = torch.bmm(a, b, out_dtype=acc)
+            _BMM_OUT_DTYPE = True
+            return out
+        except (TypeError, RuntimeError):
+            if _BMM_OUT_DTYPE:           # worked before: a real error of this call
+                raise
+            _BMM_OUT_DTYPE = False
+    return torch.bmm(a, b)
+
+
 def _weight_grad(gy, x):
     """dY^T X over row chunks: (rows, out), (rows, in) -> (out, in), at least float32."""
     acc = _acc_dtype(gy.dtype)
@@ -39,8 +62,8 @@ def _weight_grad(gy, x):
     n_chunk = max(1, rows // CHUNK_ROWS)
     per = rows // n_chunk
     body = n_chunk * per
-    part = torch.bmm(gy[:body].view(n_chunk, per, -1).transpose(1, 2),
-                     x[:body].view(n_chunk, per, -1))
+    part = _bmm_acc(gy[:body].view(n_chunk, per, -1).transpose(1, 2),
+                    x[:body].view(n_chunk, per, -1), acc)
     gw = part.sum(0, dtype=acc)
     if body < rows:                                     # the ragged tail: a short ordinary GEMM
         gw = gw + (gy[body:].t() @ x[body:]).to(acc)

@@ -263,16 +263,23 @@ class BoxAttnFromBoxesFunction(Function):
     BoxGridFunction's kernels + the plain operator instead (same results)."""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @custom_fwd(device_type="cuda")
     def forward(ctx, value, shapes, lsi, ref_windows, offsets, kernel_indices, valid_ratios,
                 angle_mode, attention_weights, native_bf16):
-        ctx.value_dtype = value.dtype
-        value = value.to(torch.bfloat16).contiguous() if native_bf16 else value.contiguous()
-        ref_windows, offsets = ref_windows.contiguous(), offsets.contiguous()
-        kernel_indices = kernel_indices.contiguous()
-        attn = attention_weights.contiguous()
+        # no cast_inputs: under autocast a bf16 value (ValueMaskCastFunction's output) would be
+        # widened to float32 by the decorator and narrowed again here -- two passes over B*S*d.
+        # custom_fwd still disables autocast inside; the geometry / weights go to float32 by hand
+        ctx.value_dtype = value.dtype                # the caller's type: grad_value goes back in it
+        if native_bf16:
+            value = value if value.dtype == torch.bfloat16 else value.to(torch.bfloat16)
+        else:
+            value = value.float()
+        value = value.contiguous()
+        ref_windows, offsets = ref_windows.float().contiguous(), offsets.float().contiguous()
+        kernel_indices = kernel_indices.float().contiguous()
+        attn = attention_weights.float().contiguous()
         if valid_ratios is not None:
-            valid_ratios = valid_ratios.contiguous()
+            valid_ratios = valid_ratios.float().contiguous()
         res = ops.box_attn_forward_from_boxes(value, shapes, lsi, ref_windows, offsets,
                                               kernel_indices, valid_ratios, angle_mode, attn)
         if res is None:                     # not a shape of the fused kernels

@@ -32,6 +32,12 @@ class build_hip(_build_ext):
 
     def run(self):
         lib = _lib_module()
+        # a copy of the C-ABI header inside the package: a non-editable install can then rebuild
+        # the compiled e2edet_ops module without the source checkout (boxer_amd/_lib.INCLUDE_DIR)
+        import shutil
+        os.makedirs(os.path.join(HERE, "boxer_amd", "include"), exist_ok=True)
+        shutil.copy2(os.path.join(HERE, "include", "boxattn.h"),
+                     os.path.join(HERE, "boxer_amd", "include", "boxattn.h"))
         path = lib.build(force=True, verbose=True)
         print("built", path)
         # the reference's pybind11 module on the C ABI (host compiler + torch headers); optional:
@@ -50,7 +56,7 @@ setup(
     version="0.1.0",
     description="MI355X-native box-attention / instance-attention operator (BoxeR drop-in)",
     packages=find_packages(include=["boxer_amd", "boxer_amd.*"]),
-    package_data={"boxer_amd": ["libboxattn_hip.so", "e2edet_ops*.so", "csrc/*"]},
+    package_data={"boxer_amd": ["libboxattn_hip.so", "e2edet_ops*.so", "csrc/*", "include/*.h"]},
     cmdclass={"build_ext": build_hip},
     python_requires=">=3.8",
 )

@@ -1089,6 +1089,29 @@ def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, 
         assert err <= tol * max(1.0, want.abs().max().item()), (name, err)
 
 
+@pytest.mark.gpu
+def test_boxes_in_backward_with_undersized_workspace(monkeypatch):
+    """ADVICE (round 2): boxattn_bwd_ws_grid_* with a workspace smaller than the binned layout must
+    report "not eligible" before anything is launched -- the atomic fallback would write
+    B*Lq*H*L*P*2 location gradients into the (smaller) grad_offsets buffer."""
+    from boxer_amd import ops
+    levels = [(48, 40), (24, 20), (12, 10), (6, 5)]
+    value, shapes, lsi, ref, off, kidx, vr, attn, gout = _box_inputs(
+        levels, 2, 8, 0, False, False, torch.float32)
+    grid = ops.box_grid_forward(ref, off, kidx, vr, 0)
+    real = ops._workspace
+
+    def small(value, shapes, lsi, dims):
+        ws, sh, ls = real(value, shapes, lsi, dims)
+        return ws[: ws.numel() // 2 // 256 * 256], sh, ls
+
+    monkeypatch.setattr(ops, "_workspace", small)
+    res = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr, 0,
+                                         need_ref_grad=True)
+    torch.cuda.synchronize()
+    assert res is None
+
+
 def test_modules_with_grid_inside_the_kernels():
     """``module.fused_grid = 2``: outputs and parameter gradients of BoxAttention / Box3dAttention
     as without it -- on an encoder-sized map (the fused kernels run) and on a small decoder shape
