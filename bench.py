@@ -495,6 +495,8 @@ def main():
     ap.add_argument("--preheat-s", type=float, default=PREHEAT_SECONDS,
                     help="untimed pre-heat before the protocol, seconds (profiling runs pass 0)")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant override (A/B)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="library tuning option (boxattn_set_option), e.g. 11=2: dense encoder kernels on")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 1 if args.workload == "C1" else BATCH
@@ -518,6 +520,9 @@ def main():
 
     from boxer_amd import _lib
     _lib.set_variant(args.variant)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.load().boxattn_set_option(int(k), int(v))
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     # every rank owns its own images (different seed): data-parallel shard, no exchange
     inp = make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch,

@@ -17,14 +17,18 @@ LIB_PATH = os.path.join(_PKG, LIB_NAME)
 INCLUDE_DIR = os.path.join(os.path.dirname(_PKG), "include")
 if not os.path.exists(os.path.join(INCLUDE_DIR, "boxattn.h")):
     INCLUDE_DIR = os.path.join(_PKG, "include")
-SOURCES = ["boxattn_capi.hip"]
+# translation units -> extra flags.  boxattn_dense.hip (the matrix-core encoder kernels) is built
+# with -fno-slp-vectorize: packed float32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32, which the
+# SLP vectoriser forms from adjacent scalar operations) issued while an MFMA of the same wave is
+# finishing returned wrong results in lanes 48-63 on MI355X with this compiler
+SOURCES = {"boxattn_capi.hip": [], "boxattn_dense.hip": ["-fno-slp-vectorize"]}
 HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments (its pointers) arrive in
 # SGPRs with the wave instead of through scalar loads at its top (gfx94x / gfx950); every wave of
 # these kernels is short, and their prologues are a measurable part of them
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-shared", "-Wall", "-Wno-pass-failed",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-pass-failed",
                "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+BUILD_DIR = os.path.join(_PKG, "_build")
 
 _lib = None
 
@@ -92,28 +96,53 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build %s" % LIB_NAME)
 
 
+def _deps():
+    deps = [os.path.join(_CSRC, f) for f in list(SOURCES) + HEADERS]
+    deps.append(os.path.join(INCLUDE_DIR, "boxattn.h"))
+    return [d for d in deps if os.path.exists(d)]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    srcs = [os.path.join(_CSRC, f) for f in SOURCES + HEADERS]
-    srcs.append(os.path.join(INCLUDE_DIR, "boxattn.h"))
-    return any(os.path.getmtime(s) > built for s in srcs if os.path.exists(s))
+    return any(os.path.getmtime(s) > built for s in _deps())
 
 
-def build(force=False, verbose=False):
-    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU)."""
-    if not (force or needs_build()):
-        return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + [
-        os.path.join(_CSRC, s) for s in SOURCES]
+def build(force=False, verbose=False, extra_flags=(), out_path=None):
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU): one object per
+    translation unit (compiled in parallel), then one shared library.  ``extra_flags`` /
+    ``out_path``: tuning builds next to the product (tools/build_variants.sh)."""
+    variant = out_path is not None
+    out_path = out_path or LIB_PATH
+    if not (force or variant or needs_build()):
+        return out_path
+    tag = os.path.basename(out_path)
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    newest = max(os.path.getmtime(d) for d in _deps())
+    procs, objs = [], []
+    for src, flags in SOURCES.items():
+        obj = os.path.join(BUILD_DIR, "%s.%s.o" % (tag, src))
+        objs.append(obj)
+        if not (force or variant) and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+            continue
+        cmd = [hipcc_path()] + HIPCC_FLAGS + list(flags) + list(extra_flags) + [
+            "-c", os.path.join(_CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    global _lib
-    _lib = None
-    return LIB_PATH
+    os.replace(out_path + ".tmp", out_path)
+    if not variant:
+        global _lib
+        _lib = None
+    return out_path
 
 
 def load():
@@ -203,3 +232,12 @@ def profile_end():
     load().boxattn_profile_end(ms, n)
     return {name: {"ms": (ms[i] / n[i] if n[i] else None), "launches": int(n[i])}
             for i, name in enumerate(PROFILE_SLOTS)}
+
+
+if __name__ == "__main__":      # python -m boxer_amd._lib [--out PATH] [extra hipcc flags ...]
+    import sys
+    args = sys.argv[1:]
+    out = None
+    if args[:1] == ["--out"]:
+        out, args = args[1], args[2:]
+    print(build(force=True, verbose=True, extra_flags=args, out_path=out))

@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "boxattn_device.h"
+#include "boxattn_combine.h"
 
 namespace boxattn {
 
@@ -74,16 +75,6 @@ __device__ __forceinline__ unsigned pack_block_geo(const BinLevel &lv, int level
     return (unsigned)oy | ((unsigned)ox << 12) | ((unsigned)(bh - 1) << 24) |
            ((unsigned)(bw - 1) << 26) | ((unsigned)level << 29);
 }
-struct BlockGeo { int oy, ox, bh, bw, level; };
-__device__ __forceinline__ BlockGeo unpack_block_geo(unsigned g)
-{
-    BlockGeo r;
-    r.oy = (int)(g & 0xFFFu); r.ox = (int)((g >> 12) & 0xFFFu);
-    r.bh = (int)((g >> 24) & 3u) + 1; r.bw = (int)((g >> 26) & 7u) + 1;
-    r.level = (int)(g >> 29);
-    return r;
-}
-
 #ifndef BOXATTN_TUNE_INTERLEAVE
 #define BOXATTN_TUNE_INTERLEAVE 1
 #endif
@@ -99,7 +90,6 @@ __device__ __forceinline__ int slice_on_xcd(int xcd, int i, int per_xcd)
     return BOXATTN_TUNE_SLICE_MAP ? xcd * per_xcd + i : xcd + 8 * i;
 }
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // bin_scan_a_kernel: sub-ranges of workgroups
-constexpr int kMaxBinLevels = 8;   // levels the binned backward plans for (BoxeR uses 2-5)
 
 struct BinPlan {
     int L;
@@ -892,11 +882,6 @@ void binned_accumulate_kernel(
 // 6: sum the partial tiles of the blocks that were cut into chunks.  grid = (workers, slices),
 //    one wavefront each, looping over the slice's chunked blocks (only the coarse levels).
 // ---------------------------------------------------------------------------------------
-// What the combine step needs of the plan (small enough to ride along in another kernel's arguments).
-struct CombinePlan {
-    int nblk, pslot_cap, n_slices;
-    int start[kMaxBinLevels], W[kMaxBinLevels];
-};
 inline CombinePlan combine_plan(const BinPlan &p)
 {
     CombinePlan c;
@@ -904,66 +889,6 @@ inline CombinePlan combine_plan(const BinPlan &p)
     for (int k = 0; k < kMaxBinLevels; ++k) { c.start[k] = p.lv[k].start; c.W[k] = p.lv[k].W; }
     return c;
 }
-// One wavefront (lane = threadIdx & 63) as worker `worker` of `n_workers` of slice s.
-template <typename ST, int C>
-__device__ __forceinline__ void combine_partials_body(const int4 *__restrict__ combos,
-                                                      const int *__restrict__ n_items,
-                                                      const float *__restrict__ partials,
-                                                      const CombinePlan &plan, int S, int H,
-                                                      ST *__restrict__ grad_value, int s, int worker,
-                                                      int n_workers, int lane)
-{
-    constexpr int BW = 8, PB = 32, CH = C / 2, EPL = 16 / (int)sizeof(ST);
-    const int b = s / H, h = s % H;
-    const int n_comb = n_items[2 * s + 1];
-    const int mypix = lane >> 1, half = lane & 1;
-    for (int ci = worker; ci < n_comb; ci += n_workers) {
-        const int4 cb = combos[(size_t)s * plan.nblk + ci];          // {block geometry, first slot, nch}
-        const BlockGeo bg = unpack_block_geo((unsigned)cb.x);
-        int lv_start = plan.start[0], lv_W = plan.W[0];
-#pragma unroll
-        for (int k = 1; k < kMaxBinLevels; ++k)
-            if (k == bg.level) { lv_start = plan.start[k]; lv_W = plan.W[k]; }
-        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
-        if (mypix / BW >= bh || mypix % BW >= bw) continue;
-        const int yy = oy + mypix / BW, xx = ox + mypix % BW;
-        float acc[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) acc[c] = 0.f;
-        const float *p0 = partials + (((size_t)s * plan.pslot_cap + cb.y) * PB + mypix) * C +
-                          half * CH;
-        for (int j0 = 0; j0 < cb.z; j0 += 4) {                  // 4 partial tiles in flight
-            float4 t[4][CH / 4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 *src = reinterpret_cast<const float4 *>(
-                    p0 + (size_t)min(j0 + u, cb.z - 1) * PB * C);
-#pragma unroll
-                for (int c = 0; c < CH / 4; ++c) t[u][c] = src[c];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j0 + u < cb.z) {
-#pragma unroll
-                    for (int c = 0; c < CH / 4; ++c) {
-                        acc[4 * c] += t[u][c].x; acc[4 * c + 1] += t[u][c].y;
-                        acc[4 * c + 2] += t[u][c].z; acc[4 * c + 3] += t[u][c].w;
-                    }
-                }
-            }
-        }
-        ST *dst = grad_value + (((size_t)b * S + lv_start + (size_t)yy * lv_W + xx) * H + h) * C +
-                  half * CH;
-#pragma unroll
-        for (int c = 0; c < CH; c += EPL) {
-            float t[EPL];
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) t[i] = acc[c + i];
-            VecIO<ST, EPL>::st(dst + c, t);
-        }
-    }
-}
-
 template <typename ST, int C>
 __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__restrict__ combos,
                                                               const int *__restrict__ n_items,

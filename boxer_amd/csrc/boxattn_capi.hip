@@ -18,6 +18,7 @@
 #include "boxattn_binned_mfma.h"
 #include "boxattn_fast.h"
 #include "boxattn_gather2.h"
+#include "boxattn_dense_plan.h"
 #include "boxattn_generic.h"
 #include "boxattn_grid.h"
 #include "boxattn_qgrid.h"
@@ -35,7 +36,10 @@ std::atomic<int> g_variant{0};
 // Tuning options (boxattn_set_option): process-wide knobs for A/B runs, relaxed atomics.
 enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStatic = 3, kOptTileAblate = 4,
        kOptQgTarget = 5, kOptTileFwd = 6, kOptQgAblate = 7, kOptQgWaves = 8, kOptQgBwd = 9, kOptBinChunk = 10,
-       kNumOpts = 12 };
+       kOptDense = 11,        // dense (matrix-core) encoder kernels: 0 default (BOXATTN_DENSE_DEFAULT), 1 off, 2 on
+       kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
+       kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
+       kNumOpts = 16 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
@@ -812,6 +816,75 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
 
 // Can the point-gradient kernel reduce the location gradients to box gradients itself (GRID
 // flavour of pointgrad2_kernel: buffered epilogue, one launch row)?
+// ------------------------------------------------- dense encoder kernels (boxattn_dense.h)
+#ifndef BOXATTN_DENSE_DEFAULT
+#define BOXATTN_DENSE_DEFAULT 0       // used without being asked for (boxattn_set_option(11, 2) switches them on)
+#endif
+std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: per-point corner sums (boxattn_set_debug_buffer)
+// Encoder case: one query per pixel of packed levels, bf16 storage, C = 32, 2x2 points, <= 4 levels.
+inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p)
+{
+    const bool want = opt(kOptDense) == 0 ? BOXATTN_DENSE_DEFAULT != 0 : opt(kOptDense) == 2;
+    if (!sh || !ls || !d.valid() || !want || g_variant == 1 || g_variant == 2) return false;
+    if (d.Lq != d.S || d.C != 32 || d.P != 4 || d.L > kDenseMaxLevels || d.B < 1 || d.S < 1) return false;
+    if ((size_t)d.B * d.Lq * d.H * d.L * d.P >= (1ull << 31)) return false;       // 32-bit point ids
+    if (d.n_value() * sizeof(bf16_t) >= kOobOffset) return false;
+    p = DensePlan{};
+    p.dbg = g_dense_dbg.load();
+    p.L = d.L; p.B = d.B; p.Lq = d.Lq; p.S = d.S; p.H = d.H;
+    p.hg = (d.H + 3) / 4;
+    p.rcp_hg = 1.0f / (float)p.hg;
+    long long next = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1];
+        if (hl <= 0 || wl <= 0 || hl > 32000 || wl > 32000 || ls[l] != next) return false;
+        next += hl * wl;
+        DenseLevel &v = p.lv[l];
+        v.H = (int)hl; v.W = (int)wl; v.start = (int)ls[l];
+        v.ntx = (int)((wl + kDenseTile - 1) / kDenseTile);
+        v.ntiles = v.ntx * (int)((hl + kDenseTile - 1) / kDenseTile);
+        if ((long long)v.ntiles * d.B >= (1 << 20)) return false;      // float divisions, x * n < 2^23
+        v.rcp_ntx = 1.0f / (float)v.ntx;
+        v.rcp_ntiles = 1.0f / (float)v.ntiles;
+    }
+    if (next != d.S) return false;
+    // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
+    // (r = W_l / W_lq); their points lie a quarter box (ref / 4 pixels of the query's level, i.e.
+    // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further
+    const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
+    const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
+    for (int lq = 0; lq < d.L; ++lq)
+        for (int l = 0; l < d.L; ++l) {
+            DenseWin &w = p.win[lq][l];
+            const float rx = (float)p.lv[l].W / (float)p.lv[lq].W, ry = (float)p.lv[l].H / (float)p.lv[lq].H;
+            const float mx = rx * ref4 * (1.0f + jit), my = ry * ref4 * (1.0f + jit);
+            const int cols = (int)std::ceil(rx * (kDenseTile - 1) + 2 * mx) + 2;
+            const int rows = (int)std::ceil(ry * (kDenseTile - 1) + 2 * my) + 2;
+            w.ax = kDenseTile * rx; w.bx = 0.5f * rx - 0.5f - mx;
+            w.ay = kDenseTile * ry; w.by = 0.5f * ry - 0.5f - my;
+            const bool fits = cols <= kDenseWin && rows <= kDenseWin;
+            w.rows = fits ? rows : 0;
+            w.cols = fits ? cols : 0;
+        }
+    return true;
+}
+
+inline bool dense_pointgrad_ok(const DensePlan *dp, const void *value, const void *loc, const void *attn,
+                               const void *grad_out, const void *grad_loc, const void *grad_attn)
+{
+    return dp && aligned(value, 16) && aligned(grad_out, 16) && aligned(loc, 8) &&
+           aligned(attn, 4) && aligned(grad_loc, 16) && aligned(grad_attn, 16);
+}
+
+inline void run_pointgrad_dense(const bf16_t *value, const float *loc, const float *attn,
+                                const bf16_t *grad_out, const Dims &d, const DensePlan &dp,
+                                float *grad_loc, float *grad_attn, hipStream_t st, const CombineTail *ct)
+{
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
+    launch_pointgrad_dense(value, loc, attn, grad_out, dp, grad_loc, grad_attn,
+                           (unsigned)(d.n_value() * sizeof(bf16_t)), st, ct ? *ct : CombineTail{});
+}
+
 template <typename ST>
 bool pointgrad_grid_ok(const Dims &d, const void *value, const void *grad_out, const void *grad_sp)
 {
@@ -830,8 +903,15 @@ template <typename ST, int G, bool INST>
 void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                       const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st,
-                      const GridSrc *gs = nullptr, const CombineTail *ct = nullptr)
+                      const GridSrc *gs = nullptr, const CombineTail *ct = nullptr,
+                      const DensePlan *dp = nullptr)
 {
+    if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
+        if (!gs && dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
+            run_pointgrad_dense(value, loc, w_sp, grad_out, d, *dp, grad_loc, grad_sp, st, ct);
+            return;
+        }
+    }
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
     const size_t n_qh = d.n_qh();
     const size_t vbytes = d.n_value() * sizeof(ST);
@@ -904,7 +984,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
                float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st,
-               const GridSrc *gs = nullptr)
+               const GridSrc *gs = nullptr, const DensePlan *dp = nullptr)
 {
     const int ns = d.B * d.H;
     int *n_items = (int *)(ws + w.n_items);
@@ -928,7 +1008,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     const bool tail = BOXATTN_TUNE_COMBINE_TAIL && side.stream() == st;
     if (!tail)
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d,
-                                      grad_loc, grad_sp, grad_lv, side.stream(), gs);
+                                      grad_loc, grad_sp, grad_lv, side.stream(), gs, nullptr, dp);
     // One single-wave workgroup per potential work item (item_cap is the host-side bound; the
     // real count lives on the device, surplus workgroups exit at once); the hardware dispatcher
     // hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
@@ -983,7 +1063,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     if (tail) {
         CombineTail ct{combos, n_items, partials, grad_value, combine_plan(plan), 64};
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d,
-                                      grad_loc, grad_sp, grad_lv, st, gs, &ct);
+                                      grad_loc, grad_sp, grad_lv, st, gs, &ct, dp);
     } else {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
         hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
@@ -1175,12 +1255,14 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         return (int)hipErrorInvalidValue;
     char *ws = (char *)workspace;
     int rc = 0;
+    DensePlan dense;
+    const DensePlan *dp = kBf16 && !INST && make_dense_plan(d, shapes_host, lsi_host, dense) ? &dense : nullptr;
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
-                                      plan_ready, st, gs);                                      \
+                                      plan_ready, st, gs, dp);                                  \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -1381,6 +1463,10 @@ int boxattn_profile_end(double *ms_sum, int *launches)
 }
 
 int boxattn_set_variant(int variant) { return g_variant.exchange(variant); }
+
+// debugging aid, not part of the documented ABI: a device buffer of 8 floats per sample point that the
+// dense point-gradient kernel fills with its corner sums (nullptr: off)
+void boxattn_set_debug_buffer(float *p) { g_dense_dbg.store(p); }
 
 int boxattn_set_option(int key, int value)
 {

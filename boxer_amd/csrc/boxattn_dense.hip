@@ -1,0 +1,26 @@
+// Translation unit of the dense (matrix-core) encoder kernels.  Built with -fno-slp-vectorize
+// (boxer_amd/_lib.py SOURCES): no packed float32 VALU instructions next to the MFMAs.
+#include "boxattn_dense.h"
+
+namespace boxattn {
+
+void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float *attn,
+                            const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
+                            float *grad_attn, unsigned value_bytes, hipStream_t st,
+                            const CombineTail &tail)
+{
+    const unsigned tail_blocks = tail.workers > 0 ? (unsigned)(tail.workers * tail.plan.n_slices + 3) / 4 : 0;
+    const unsigned blocks = dense_blocks(dp);
+#define BOXATTN_DENSE_PG(LV_)                                                                           \
+    case LV_:                                                                                           \
+        hipLaunchKernelGGL((pointgrad_dense_kernel<LV_>), dim3(blocks + tail_blocks), dim3(256), 0, st, \
+                           value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes, blocks,    \
+                           tail);                                                                       \
+        break;
+    switch (dp.L) {
+        BOXATTN_DENSE_PG(1) BOXATTN_DENSE_PG(2) BOXATTN_DENSE_PG(3) BOXATTN_DENSE_PG(4)
+    }
+#undef BOXATTN_DENSE_PG
+}
+
+}  // namespace boxattn

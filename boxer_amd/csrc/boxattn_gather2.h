@@ -661,21 +661,6 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     if (grp == 0) row_store<ST, VEC, PSB>(out + (size_t)qh * C + slot * LCH, acc);
 }
 
-// The combine step of the binned backward (sum the partial tiles of the chunked blocks,
-// boxattn_binned.h step 6) riding along in the point-gradient launch: `workers` single-wave workers
-// per slice are appended to the grid as extra workgroups.  The two have nothing to do with each
-// other except that the point gradients are the LAST kernel of the backward once they are launched
-// after the accumulate kernel -- and a launch of its own for a few hundred waves of work is 5-7 us
-// of every step (a tenth of a decoder-shaped one).
-struct CombineTail {
-    const int4 *combos;
-    const int *n_items;
-    const float *partials;
-    void *grad_value;
-    CombinePlan plan;
-    int workers;          // per slice; 0: no combine work in this launch
-};
-
 // ---------------------------------------------------------------------------------------
 // backward, point gradients only (grad_loc, grad_weight[s]); grad_value is boxattn_binned.h
 // ---------------------------------------------------------------------------------------

