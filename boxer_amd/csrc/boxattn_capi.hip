@@ -832,8 +832,7 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
     p = DensePlan{};
     p.dbg = g_dense_dbg.load();
     p.L = d.L; p.B = d.B; p.Lq = d.Lq; p.S = d.S; p.H = d.H;
-    p.hg = (d.H + 3) / 4;
-    p.rcp_hg = 1.0f / (float)p.hg;
+    p.rcp_h = 1.0f / (float)d.H;
     long long next = 0;
     for (int l = 0; l < d.L; ++l) {
         const long long hl = sh[2 * l], wl = sh[2 * l + 1];
@@ -843,18 +842,21 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
         v.H = (int)hl; v.W = (int)wl; v.start = (int)ls[l];
         v.ntx = (int)((wl + kDenseTile - 1) / kDenseTile);
         v.ntiles = v.ntx * (int)((hl + kDenseTile - 1) / kDenseTile);
-        if ((long long)v.ntiles * d.B >= (1 << 20)) return false;      // float divisions, x * n < 2^23
+        if ((long long)v.ntiles * d.B * d.H >= (1 << 20)) return false;      // float divisions, x * n < 2^23
         v.rcp_ntx = 1.0f / (float)v.ntx;
         v.rcp_ntiles = 1.0f / (float)v.ntiles;
     }
     if (next != d.S) return false;
     // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
     // (r = W_l / W_lq); their points lie a quarter box (ref / 4 pixels of the query's level, i.e.
-    // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further
+    // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further.
+    // The levels are staged coarsest first into the workgroup's kDenseSlots pixel slots; what does
+    // not fit (a coarse tile's window on a fine level) is not staged.
     const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
     const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
-    for (int lq = 0; lq < d.L; ++lq)
-        for (int l = 0; l < d.L; ++l) {
+    for (int lq = 0; lq < d.L; ++lq) {
+        int used = 0;
+        for (int l = d.L - 1; l >= 0; --l) {
             DenseWin &w = p.win[lq][l];
             const float rx = (float)p.lv[l].W / (float)p.lv[lq].W, ry = (float)p.lv[l].H / (float)p.lv[lq].H;
             const float mx = rx * ref4 * (1.0f + jit), my = ry * ref4 * (1.0f + jit);
@@ -862,10 +864,15 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             const int rows = (int)std::ceil(ry * (kDenseTile - 1) + 2 * my) + 2;
             w.ax = kDenseTile * rx; w.bx = 0.5f * rx - 0.5f - mx;
             w.ay = kDenseTile * ry; w.by = 0.5f * ry - 0.5f - my;
-            const bool fits = cols <= kDenseWin && rows <= kDenseWin;
+            const int pitch = cols + 2;             // slots of neighbouring rows start 2 bank groups apart
+            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots;
             w.rows = fits ? rows : 0;
             w.cols = fits ? cols : 0;
+            w.pitch = pitch;
+            w.off = used;
+            if (fits) used += rows * pitch;
         }
+    }
     return true;
 }
 

@@ -1,28 +1,32 @@
-// Dense (matrix-core) kernels for the ENCODER case of box attention: one query per pixel
-// (Lq == S, packed levels), bf16 storage, C = 32 channels per head, 2x2 points per level.
+// Window-staged kernels for the ENCODER case of box attention: one query per pixel (Lq == S, packed
+// levels), bf16 storage, C = 32 channels per head, 2x2 points per level.
 //
-// The gather kernels (boxattn_gather2.h) pull 4 corner rows per sample point through the vector
-// L1 -- 64 rows per (query, head) -- and sit at the rate the L1 can deliver rows.
-// In the encoder the queries are the pixels, a query's boxes lie around its own position on every
-// level, so the rows a 4x4 TILE of queries touches on one level form a small window (12x12 pixels
-// on the tile's own level, 7x7 / 5x5 / 4x4 on the coarser ones).  These kernels work on
-// (tile, head) pairs, one wavefront each, and replace the per-point row gathers by products on the
-// matrix cores over the window:
+// The gather kernels (boxattn_gather2.h) pull 4 corner rows per sample point through the vector L1
+// -- 64 rows per (query, head) -- and sit at the rate at which the L1 gets rows out of the L2
+// (DESIGN.md 4.1).  In the encoder the queries are the pixels and a query's boxes lie around its own
+// position on every level, so the rows an 8x8 TILE of queries touches on one level form a small
+// window: 16x16 pixels on the tile's own level, 9x9 / 6x6 / 4x4 on the coarser ones -- 389 rows for
+// 64 queries x 64 corner rows.  One workgroup = one (tile, head): its four waves fetch the windows of
+// all levels once, as whole coalesced rows, into LDS (38 KB), and after ONE barrier every lane works
+// alone:
 //
-//   point gradients   S[q][pix] = sum_c G[q][c] V[pix][c]     (v_mfma_f32_16x16x32_bf16: M = the 16
-//                     queries, N = 16 pixels of one window row, K = the 32 channels; both operands
-//                     are natural 16-byte pieces of a grad_out / value row, straight from memory),
-//                     S goes to wave-private LDS and every sample point picks its four corners:
-//                     grad_w = sum_k w_k S_k, grad_x / grad_y from the corner differences
-//                     (reference box_attn_kernel.cuh:145-183 with the channel sum pulled out).
+//   lane = one sample point of one query (wave = 4x4 sub-tile of queries x the 2x2 points), the
+//   levels one after the other.  A lane reads the four corner rows of its point from LDS (64 bytes
+//   each, 4 x ds_read_b128) and multiplies them with its query's grad_out row, which it keeps in 16
+//   registers: 16 v_dot2c_f32_bf16 per corner, no cross-lane step at all (the gather kernels spread
+//   a row over 4 lanes because a lane per row is poison for the vector L1; from LDS it is free).
 //
-// Lane = (query of the tile, point of the 2x2 grid); the levels are walked one after the other.
-// The window of (tile, level) is placed by geometry alone (wave-uniform, no reductions): the tile's
-// position projected onto the level plus a margin for the box size and its predicted offset.  That
-// placement is a performance heuristic only: a point whose footprint is not inside the window takes
-// the per-lane slow path (its four rows fetched and multiplied out by the lane itself), levels whose
-// window would not fit (a coarse tile looking at a fine level) take it for every point -- results
-// are the same either way, for any input.
+// The window of (tile, level) is placed by geometry alone (wave-uniform): the tile's position
+// projected onto the level plus a margin for the box size and its predicted offset.  Placement and
+// staging are a performance matter only: a point whose footprint is not inside its staged window --
+// and every point of a level whose window is not staged (a coarse tile looking at a fine level: too
+// large) -- takes the global path, the same dot products on rows fetched by the lane itself.  The
+// results are the same either way, for any input.
+//
+// (Round 3 first built this on the matrix cores -- S = G V^T per 4x4 tile and window row on
+// v_mfma_f32_16x16x32_bf16, look-ups from an S tile in LDS: tools/experiments/boxattn_dense_mfma_v1.h.
+// Parity-green, 61 us against the gather kernel's 48: with a wave-private 12x12 window per 4x4 tile
+// the L2 -> L1 traffic is the gather kernel's, and that traffic is what bounds both.)
 #pragma once
 #include "boxattn_device.h"
 #include "boxattn_combine.h"      // CombineTail: the combine step's workers ride in this launch too
@@ -31,11 +35,9 @@
 namespace boxattn {
 
 #ifndef BOXATTN_DENSE_DEBUG
-#define BOXATTN_DENSE_DEBUG 0     // 1: the point-gradient kernel dumps its corner sums (DensePlan::dbg)
+#define BOXATTN_DENSE_DEBUG 0     // 2: s_memtime stamps of every wave (tools/gpu_dense_trace.py, DensePlan::dbg)
 #endif
 typedef unsigned int dense_u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 dense_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float dense_f32x4 __attribute__((ext_vector_type(4)));
 
 // n / d, n % d for 0 <= n < 2^24 (float estimate + correction), d > 0
 __device__ __forceinline__ void dense_divmod(unsigned n, int d, float rcp, unsigned &q, unsigned &r)
@@ -48,25 +50,39 @@ __device__ __forceinline__ void dense_divmod(unsigned n, int d, float rcp, unsig
     r = (unsigned)__builtin_amdgcn_readfirstlane(ri);
 }
 
-// one 64-byte row (32 bf16 channels) as 16 words
-__device__ __forceinline__ void dense_load_row(const bf16_t *p, unsigned (&w)[16])
+// one 64-byte row (32 bf16 channels) as 16 words.  (The words go through a plain array: a bit_cast
+// of element i of an ext_vector selects element 0 for every i with this compiler)
+template <typename PTR> __device__ __forceinline__ void dense_load_row(PTR p, unsigned (&w)[16])
 {
-    const dense_u32x4 *q = reinterpret_cast<const dense_u32x4 *>(p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const dense_u32x4 t = q[i];
+        const dense_u32x4 t = reinterpret_cast<const dense_u32x4 *>(p)[i];
         w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
     }
 }
+__device__ __forceinline__ float dense_dot_row(const unsigned (&g)[16], const unsigned (&v)[16])
+{
+    // bf16 x bf16 products are exact in fp32; two chains: a v_dot2c waits for its own accumulator
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        d0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, g[i]),
+                                             __builtin_bit_cast(bf16x2_t, v[i]), d0, false);
+        d1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, g[i + 1]),
+                                             __builtin_bit_cast(bf16x2_t, v[i + 1]), d1, false);
+    }
+    return d0 + d1;
+}
 
-// Which (tile, head group) a workgroup works on.  Workgroup w runs on XCD w % 8 (observed placement;
-// only speed depends on it): every XCD gets one contiguous eighth of every level's tiles -- its L2
-// then holds one spatial band of the maps -- and walks the levels coarsest first, because the tiles
-// of the coarse levels are the slow ones (their fine-level points all take the slow path).
+// Which (tile, head) a workgroup works on.  Workgroup w runs on XCD w % 8 (observed placement; only
+// speed depends on it): every XCD gets one contiguous eighth of every level's tiles, all heads of a
+// tile (the two 64-byte halves of a value line belong to neighbouring heads) -- its L2 then holds one
+// spatial band of the maps -- and walks the levels coarsest first, because the tiles of the coarse
+// levels are the slow ones (their fine-level points take the global path).
 struct DenseTileId {
     int lq;                  // query level, -1: no tile
     unsigned b;
-    int ty, tx, hg;
+    int ty, tx, h;
 };
 template <int L>
 __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, unsigned block)
@@ -74,9 +90,9 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
     DenseTileId t;
     t.lq = -1;
     const unsigned x = block & 7u;
-    unsigned j, hg;
-    dense_divmod(block >> 3, pl.hg, pl.rcp_hg, j, hg);
-    t.hg = (int)hg;
+    unsigned j, h;
+    dense_divmod(block >> 3, pl.H, pl.rcp_h, j, h);
+    t.h = (int)h;
     unsigned ti = 0;
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
@@ -102,21 +118,119 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
     return t;
 }
 
-// One workgroup = 4 wavefronts = 4 heads of one tile; the waves do not talk to each other (wave-
-// private LDS, no workgroup barrier).
-//   lds: S[plane 4][pixel 144][4 queries] float, S[q][pix] at plane q / 4, slot q % 4: the MFMA's
-//   result registers (4 consecutive queries of one pixel per lane) go out as one 16-byte write per
-//   lane, lanes of one instruction on consecutive 16-byte slots.
-constexpr int kDenseLdsFloats = 4 * kDensePix * 4;
+// Placement of a tile's windows (wave-uniform) and the cooperative fetch: wave w takes the window rows
+// w, w + 4, ... of every level; a row of up to 16 pixels x 64 bytes is one load instruction (4 lanes
+// per pixel).  Returns with the rows in LDS and the workgroup past its barrier.
+struct DenseWinPos { int rows, cols, pitch, off, x0, y0; };
+
+template <int L> struct DenseStageRegs { dense_u32x4 reg[L][kDenseWinMax / 4]; };
 
 template <int L>
-__global__ __launch_bounds__(256) void pointgrad_dense_kernel(
+__device__ __forceinline__ void dense_stage_issue(const DensePlan &pl, const DenseTileId &t, int lane,
+                                                  int wv, __amdgpu_buffer_rsrc_t rs, DenseWinPos (&win)[L],
+                                                  DenseStageRegs<L> &st)
+{
+    constexpr int C = 32, RPW = kDenseWinMax / 4;              // rows per wave and level at most
+    const int j = lane >> 2, chunk = lane & 3;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const DenseLevel T = pl.lv[l];
+        const DenseWin w = pl.win[t.lq][l];
+        DenseWinPos &o = win[l];
+        o.rows = w.rows; o.cols = w.cols; o.pitch = w.pitch; o.off = w.off;
+        const int x0 = (int)floorf((float)t.tx * w.ax + w.bx), y0 = (int)floorf((float)t.ty * w.ay + w.by);
+        o.x0 = __builtin_amdgcn_readfirstlane(max(0, min(x0, T.W - w.cols)));
+        o.y0 = __builtin_amdgcn_readfirstlane(max(0, min(y0, T.H - w.rows)));
+        const int jx = min(o.x0 + j, T.W - 1);
+        const unsigned voff =
+            ((((t.b * (unsigned)pl.S + (unsigned)(T.start + jx)) * (unsigned)pl.H + (unsigned)t.h) * C) +
+             (unsigned)chunk * 8u) * 2u;
+        const unsigned row_bytes = (unsigned)T.W * (unsigned)pl.H * (C * 2u);
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int r = wv + 4 * k;
+            if (r < o.rows) {                                          // wave-uniform
+                const unsigned soff = (unsigned)min(o.y0 + r, T.H - 1) * row_bytes;
+                st.reg[l][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            }
+        }
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned char *lds,
+                                                   const DenseWinPos (&win)[L], const DenseStageRegs<L> &st)
+{
+    constexpr int RPW = kDenseWinMax / 4;
+    const int j = lane >> 2, chunk = lane & 3;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const DenseWinPos &o = win[l];
+        unsigned char *dst = lds + __mul24(o.off + j, kDenseSlotBytes) + chunk * 16;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int r = wv + 4 * k;
+            if (r < o.rows && j < o.cols)
+                *reinterpret_cast<dense_u32x4 *>(dst + __mul24(r * o.pitch, kDenseSlotBytes)) = st.reg[l][k];
+        }
+    }
+    __syncthreads();
+}
+
+// The four corner sums S_k = sum_c g_c v_k,c of one sample point: from the staged window where its
+// footprint lies inside, else from global memory (`slow`, decided per lane, entered per wave).
+__device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const DenseWinPos &o,
+                                                  const unsigned char *lds, const unsigned (&gw)[16],
+                                                  const bf16_t *value, size_t row0, int H, int h, bool vq,
+                                                  float (&sk)[4])
+{
+    constexpr int C = 32;
+    const int r0 = s.y0 - o.y0, c0 = s.x0 - o.x0;                  // window coordinates of corner 1
+    const bool in_r0 = r0 >= 0 && r0 < o.rows, in_r1 = r0 + 1 >= 0 && r0 + 1 < o.rows;
+    const bool in_c0 = c0 >= 0 && c0 < o.cols, in_c1 = c0 + 1 >= 0 && c0 + 1 < o.cols;
+    const bool in[4] = {in_r0 && in_c0, in_r0 && in_c1, in_r1 && in_c0, in_r1 && in_c1};
+    const bool slow = vq && ((s.ok[0] && !in[0]) || (s.ok[1] && !in[1]) || (s.ok[2] && !in[2]) ||
+                             (s.ok[3] && !in[3]));
+    if (o.rows > 0) {                                              // wave-uniform
+        const int rr0 = min(max(r0, 0), o.rows - 1), rr1 = min(max(r0 + 1, 0), o.rows - 1);
+        const int cc0 = min(max(c0, 0), o.cols - 1), cc1 = min(max(c0 + 1, 0), o.cols - 1);
+        const int row0s = o.off + __mul24(rr0, o.pitch), row1s = o.off + __mul24(rr1, o.pitch);
+        const int slot[4] = {row0s + cc0, row0s + cc1, row1s + cc0, row1s + cc1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned vw[16];
+            dense_load_row(lds + __mul24(slot[k], kDenseSlotBytes), vw);
+            const float d = dense_dot_row(gw, vw);
+            sk[k] = (s.ok[k] && in[k]) ? d : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sk[k] = 0.f;
+    }
+    if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {               // wave-uniform
+        if (slow) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned vw[16];
+                dense_load_row(value + ((row0 + (unsigned)s.pix[k]) * H + h) * C, vw);
+                const float d = dense_dot_row(gw, vw);
+                sk[k] = s.ok[k] ? d : 0.f;
+            }
+        }
+    }
+}
+
+constexpr int kDenseResFloats = 16 * 16 * 3;       // per wave: the results of 16 queries x 16 points
+
+template <int L>
+__global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
     const bf16_t *__restrict__ grad_out, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
     DensePlan pl, unsigned value_bytes, unsigned tile_blocks, CombineTail ct)
 {
     constexpr int C = 32, P = 4, LP = L * P;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][kDenseLdsFloats];
+    __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
+    static_assert(4 * kDenseResFloats * sizeof(float) <= sizeof(win_lds), "the result tiles reuse the window buffer");
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     if (blockIdx.x >= tile_blocks) {                  // the appended combine workgroups (pointgrad2_kernel)
         if (ct.workers > 0) {
@@ -129,22 +243,36 @@ __global__ __launch_bounds__(256) void pointgrad_dense_kernel(
         }
         return;
     }
-    float *lds = lds_all[wv];
-
+#if BOXATTN_DENSE_DEBUG == 2
+    unsigned long long ts[8];
+    int ts_n = 0;
+#define DENSE_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts[ts_n++] = __builtin_amdgcn_s_memtime(); \
+                           __builtin_amdgcn_sched_barrier(0); } while (0)
+    DENSE_STAMP();
+#else
+#define DENSE_STAMP() do { } while (0)
+#endif
     const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x);
-    if (t.lq < 0) return;
-    const int H = pl.H, h = t.hg * 4 + wv;
-    if (h >= H) return;                                            // wave-uniform
+    if (t.lq < 0) return;                                          // workgroup-uniform
+    const int H = pl.H, h = t.h;
     const DenseLevel Q = pl.lv[t.lq];
 
-    // ---- lane -> (query of the tile, point)
+    // ---- lane -> (query of the wave's 4x4 sub-tile, point)
     const int qi = lane >> 2, p = lane & 3;
-    const int qy = t.ty * kDenseTile + (qi >> 2), qx = t.tx * kDenseTile + (qi & 3);
+    const int qy = t.ty * kDenseTile + (wv >> 1) * kDenseSub + (qi >> 2);
+    const int qx = t.tx * kDenseTile + (wv & 1) * kDenseSub + (qi & 3);
     const bool vq = qy < Q.H && qx < Q.W;
     const unsigned q = (unsigned)(Q.start + min(qy, Q.H - 1) * Q.W + min(qx, Q.W - 1));
     const unsigned qh = (t.b * (unsigned)pl.Lq + q) * (unsigned)H + (unsigned)h;
     const unsigned pt0 = qh * (unsigned)LP;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(value), 0, value_bytes, 0x00020000);
+    // the window rows first: they are what the workgroup's barrier waits for; the lane's own inputs
+    // (locations, weights, grad_out row) are requested behind them and land while the rows are staged
+    DenseWinPos win[L];
+    DenseStageRegs<L> stage;
+    dense_stage_issue<L>(pl, t, lane, wv, rs, win, stage);
     float2 xy[L];
     float a[L];
 #pragma unroll
@@ -152,149 +280,33 @@ __global__ __launch_bounds__(256) void pointgrad_dense_kernel(
         xy[l] = loc2[pt0 + l * P + p];
         a[l] = attn[pt0 + l * P + p];
     }
-    // ---- the A operand: row i = lane & 15 (query i of the tile), channels 8 (lane >> 4) ..
-    dense_bf16x8 gfrag;
-    {
-        const int i = lane & 15;
-        const int yi = min(t.ty * kDenseTile + (i >> 2), Q.H - 1);
-        const int xi = min(t.tx * kDenseTile + (i & 3), Q.W - 1);
-        const unsigned qhi =
-            (t.b * (unsigned)pl.Lq + (unsigned)(Q.start + yi * Q.W + xi)) * (unsigned)H + (unsigned)h;
-        gfrag = __builtin_bit_cast(dense_bf16x8, *reinterpret_cast<const dense_u32x4 *>(
-                                                     grad_out + (size_t)qhi * C + (lane >> 4) * 8));
-    }
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(value), 0, value_bytes, 0x00020000);
-
-    // The window of level l: wave-uniform placement, its rows fetched in chunks of 4 (rows past the
-    // window's last one repeat it: their results land in unused rows of the LDS tile).  The loads of
-    // level l + 1 are issued before the look-ups of level l, so that a wave always has one level's
-    // rows in flight behind its arithmetic.
-    struct Win { int rows, cols, x0, y0; };
-    Win win[L];
-    dense_u32x4 rowreg[kDenseWin];
-    auto issue = [&](int l) {
-        const DenseLevel T = pl.lv[l];
-        const DenseWin w = pl.win[t.lq][l];
-        Win &o = win[l];
-        o.rows = w.rows;
-        o.cols = w.cols;
-        const int x0 = (int)floorf((float)t.tx * w.ax + w.bx), y0 = (int)floorf((float)t.ty * w.ay + w.by);
-        o.x0 = __builtin_amdgcn_readfirstlane(max(0, min(x0, T.W - w.cols)));
-        o.y0 = __builtin_amdgcn_readfirstlane(max(0, min(y0, T.H - w.rows)));
-        const int jx = min(o.x0 + (lane & 15), T.W - 1);
-        const unsigned voff =
-            ((((t.b * (unsigned)pl.S + (unsigned)(T.start + o.y0 * T.W + jx)) * (unsigned)H + (unsigned)h) * C) +
-             (unsigned)(lane >> 4) * 8u) * 2u;
-        const unsigned row_bytes = (unsigned)T.W * (unsigned)H * (C * 2u);
-#pragma unroll
-        for (int c = 0; c < kDenseWin / 4; ++c)
-            if (c * 4 < o.rows) {                                  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int n = min(c * 4 + k, o.rows - 1);
-                    const unsigned soff = (unsigned)(min(o.y0 + n, T.H - 1) - o.y0) * row_bytes;
-                    rowreg[c * 4 + k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-                }
-            }
-    };
-    auto consume = [&](int l) {                                    // rows -> S tile in LDS
-        const Win &o = win[l];
-        const int j = lane & 15;
-        float *dst = lds + (((lane >> 4) * kDensePix + j) << 2);
-        const bool wr_lane = j < kDenseStride;
-#pragma unroll
-        for (int c = 0; c < kDenseWin / 4; ++c)
-            if (c * 4 < o.rows) {
-                dense_f32x4 acc[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        gfrag, __builtin_bit_cast(dense_bf16x8, rowreg[c * 4 + k]),
-                        dense_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                if (wr_lane) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        *reinterpret_cast<dense_f32x4 *>(dst + (c * 4 + k) * (kDenseStride * 4)) = acc[k];
-                }
-            }
-    };
+    unsigned gw[16];                                               // the query's grad_out row
+    dense_load_row(grad_out + (size_t)qh * C, gw);
+    dense_stage_commit<L>(lane, wv, win_lds, win, stage);
+    DENSE_STAMP();
 
     float ga[L], gx[L], gy[L];
-    issue(0);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const DenseLevel T = pl.lv[l];
         const Sample<float> s = locate<float>(xy[l].x, xy[l].y, T.H, T.W);
-        const int wr = win[l].rows, wc = win[l].cols, wx0 = win[l].x0, wy0 = win[l].y0;
-        if (wr > 0) {
-            wave_lds_sync();                                       // the previous level's look-ups are done
-            consume(l);
-            wave_lds_sync();
-        }
-        if (l + 1 < L) issue(l + 1);
-        // ---- the point's four corners
-        float s1, s2, s3, s4;
-        bool slow = false;
-        {
-            const int r0 = s.y0 - wy0, c0 = s.x0 - wx0;            // window coordinates of corner 1
-            const bool in_r0 = r0 >= 0 && r0 < wr, in_r1 = r0 + 1 >= 0 && r0 + 1 < wr;
-            const bool in_c0 = c0 >= 0 && c0 < wc, in_c1 = c0 + 1 >= 0 && c0 + 1 < wc;
-            const bool i1 = in_r0 && in_c0, i2 = in_r0 && in_c1, i3 = in_r1 && in_c0, i4 = in_r1 && in_c1;
-            slow = vq && ((s.ok[0] && !i1) || (s.ok[1] && !i2) || (s.ok[2] && !i3) || (s.ok[3] && !i4));
-            const int rr0 = min(max(r0, 0), kDenseWin - 1), rr1 = min(max(r0 + 1, 0), kDenseWin - 1);
-            const int cc0 = min(max(c0, 0), kDenseWin - 1), cc1 = min(max(c0 + 1, 0), kDenseWin - 1);
-            const float *src = lds + (qi >> 2) * (kDensePix * 4) + (qi & 3);
-            const float v1 = src[(rr0 * kDenseStride + cc0) * 4], v2 = src[(rr0 * kDenseStride + cc1) * 4];
-            const float v3 = src[(rr1 * kDenseStride + cc0) * 4], v4 = src[(rr1 * kDenseStride + cc1) * 4];
-            s1 = (s.ok[0] && i1) ? v1 : 0.f;
-            s2 = (s.ok[1] && i2) ? v2 : 0.f;
-            s3 = (s.ok[2] && i3) ? v3 : 0.f;
-            s4 = (s.ok[3] && i4) ? v4 : 0.f;
-        }
-        if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {           // wave-uniform
-            if (slow) {
-                // the lane's own dot products: its query's grad_out row against the four corner rows
-                // (the words go through plain arrays: a bit_cast of element i of an ext_vector
-                // selects element 0 for every i with this compiler)
-                unsigned gw[16];
-                dense_load_row(grad_out + (size_t)qh * C, gw);
-                const unsigned row0 = t.b * (unsigned)pl.S + (unsigned)T.start;
-                float sk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    unsigned vw[16];
-                    dense_load_row(value + ((size_t)(row0 + (unsigned)s.pix[k]) * H + h) * C, vw);
-                    float d = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gw[i]),
-                                                            __builtin_bit_cast(bf16x2_t, vw[i]), d, false);
-                    sk[k] = s.ok[k] ? d : 0.f;
-                }
-                s1 = sk[0]; s2 = sk[1]; s3 = sk[2]; s4 = sk[3];
-            }
-        }
-        if (BOXATTN_DENSE_DEBUG && pl.dbg && vq) {
-            float *o = pl.dbg + (size_t)(pt0 + l * P + p) * 8;
-            o[0] = s1; o[1] = s2; o[2] = s3; o[3] = s4;
-            o[4] = slow ? 1.f : 0.f;
-            o[5] = xy[l].x; o[6] = (float)s.x0; o[7] = (float)wx0;
-        }
-        // ---- finish
+        float sk[4];
+        dense_corner_sums(s, win[l], win_lds, gw, value, (size_t)t.b * pl.S + T.start, H, h, vq, sk);
         const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
-        const float gs_ = w1 * s1 + w2 * s2 + w3 * s3 + w4 * s4;
-        const float gx_ = (float)T.W * a[l] * (s.hh * (s2 - s1) + s.lh * (s4 - s3));
-        const float gy_ = (float)T.H * a[l] * (s.hw * (s3 - s1) + s.lw * (s4 - s2));
+        const float gs_ = w1 * sk[0] + w2 * sk[1] + w3 * sk[2] + w4 * sk[3];
+        const float gx_ = (float)T.W * a[l] * (s.hh * (sk[1] - sk[0]) + s.lh * (sk[3] - sk[2]));
+        const float gy_ = (float)T.H * a[l] * (s.hw * (sk[2] - sk[0]) + s.lw * (sk[3] - sk[1]));
         ga[l] = s.inside ? gs_ : 0.f;
         gx[l] = s.inside ? gx_ : 0.f;
         gy[l] = s.inside ? gy_ : 0.f;
     }
+    DENSE_STAMP();
     // ---- results: lane (q, p) holds its point on every level; memory wants, per (query, head),
-    //      [level][point] runs -- transposed through LDS so that lane (q, j) writes level j's 4 points
-    //      as 16 + 32 contiguous bytes (whole 64- / 128-byte runs per query)
-    wave_lds_sync();
-    float *res_a = lds + qi * LP, *res_xy = lds + 16 * LP + qi * LP * 2;
+    //      [level][point] runs -- transposed through (wave-private) LDS so that lane (q, j) writes
+    //      level j's 4 points as 16 + 32 contiguous bytes (whole 64- / 128-byte runs per query)
+    __syncthreads();                                               // every wave is done with the windows
+    float *res = reinterpret_cast<float *>(win_lds) + wv * kDenseResFloats;
+    float *res_a = res + qi * LP, *res_xy = res + 16 * LP + qi * LP * 2;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         res_a[l * P + p] = ga[l];
@@ -310,6 +322,17 @@ __global__ __launch_bounds__(256) void pointgrad_dense_kernel(
         gl[0] = o_0;
         gl[1] = o_1;
     }
+#if BOXATTN_DENSE_DEBUG == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DENSE_STAMP();
+    if (pl.dbg && lane == 0) {
+        float *o = pl.dbg + ((size_t)blockIdx.x * 4 + wv) * 20;
+        o[0] = (float)t.lq;
+        o[1] = (float)(unsigned)(ts[0] & 0xffffffu);
+        for (int i = 1; i < ts_n; ++i) o[1 + i] = (float)(unsigned)(ts[i] - ts[0]);
+        o[19] = (float)ts_n;
+    }
+#endif
 }
 
 }  // namespace boxattn

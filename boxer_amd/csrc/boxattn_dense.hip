@@ -1,5 +1,5 @@
-// Translation unit of the dense (matrix-core) encoder kernels.  Built with -fno-slp-vectorize
-// (boxer_amd/_lib.py SOURCES): no packed float32 VALU instructions next to the MFMAs.
+// Translation unit of the window-staged encoder kernels (boxattn_dense.h).  Built with
+// -fno-slp-vectorize (boxer_amd/_lib.py SOURCES).
 #include "boxattn_dense.h"
 
 namespace boxattn {

@@ -1,6 +1,6 @@
-// Plan (host-computed, passed by value) and launch interface of the dense encoder kernels
-// (boxattn_dense.h).  The kernels live in a translation unit of their own (boxattn_dense.hip, built
-// with -fno-slp-vectorize, see boxer_amd/_lib.py); boxattn_capi.hip only sees this header.
+// Plan (host-computed, passed by value) and launch interface of the window-staged encoder kernels
+// (boxattn_dense.h).  The kernels live in a translation unit of their own (boxattn_dense.hip, see
+// boxer_amd/_lib.py); boxattn_capi.hip only sees this header.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,14 +8,13 @@
 
 namespace boxattn {
 
-#ifndef BOXATTN_DENSE_STRIDE
-#define BOXATTN_DENSE_STRIDE 12   // pixels per stored window row: 12 (lanes of columns 12-15 do not store) or 16
-#endif
-constexpr int kDenseStride = BOXATTN_DENSE_STRIDE;
 constexpr int kDenseMaxLevels = 4;
-constexpr int kDenseWin = 12;                         // window rows / columns (at most)
-constexpr int kDenseTile = 4;                         // queries per tile side
-constexpr int kDensePix = kDenseWin * kDenseStride;   // stored pixels of a full window
+constexpr int kDenseTile = 8;              // queries per tile side: one workgroup = 8x8 queries x one head
+constexpr int kDenseSub = 4;               // ... = 2x2 sub-tiles of 4x4 queries, one wavefront each
+constexpr int kDenseWinMax = 16;           // window rows / columns at most (one wave-load per window row)
+constexpr int kDenseSlotBytes = 80;        // one staged pixel: 64 bytes of bf16 channels + 16 bytes of padding
+                                           // (bank = 20 slot + 4 chunk mod 64: 16 consecutive slots, 16 bank groups)
+constexpr int kDenseSlots = 480;           // staged pixels per workgroup (38 400 bytes)
 
 struct DenseLevel {
     int H, W, start;         // map size, first row of the level in `value`
@@ -23,23 +22,21 @@ struct DenseLevel {
     float rcp_ntx, rcp_ntiles;
 };
 // window of level l for a tile of level lq: first column floor(tx * ax + bx) (tx = tile column),
-// first row floor(ty * ay + by), clamped into the map; rows == 0: no window (slow path only)
+// first row floor(ty * ay + by), clamped into the map; rows == 0: not staged (global path only).
+// Staged pixel (r, c) of the window lives in slot off + r * pitch + c.
 struct DenseWin {
     float ax, bx, ay, by;
-    int rows, cols;
+    int rows, cols, pitch, off;
 };
 struct DensePlan {
     int L, B, Lq, S, H;
-    int hg;                  // head groups of 4 (one workgroup = one tile x 4 heads)
-    float rcp_hg;
+    float rcp_h;
     DenseLevel lv[kDenseMaxLevels];
     DenseWin win[kDenseMaxLevels][kDenseMaxLevels];      // [query level][sampled level]
-    float *dbg;              // debugging aid (builds with BOXATTN_DENSE_DEBUG; boxattn_set_debug_buffer):
-                             // 8 floats per sample point
+    float *dbg;              // debugging aid (builds with BOXATTN_DENSE_DEBUG; boxattn_set_debug_buffer)
 };
 
-
-// workgroups of the dense kernels: 8 XCD queues x head groups x the longest queue (dense_tile_of_block)
+// workgroups of the kernels: 8 XCD queues x heads x the longest queue (dense_tile_of_block)
 inline unsigned dense_blocks(const DensePlan &p)
 {
     unsigned longest = 0;
@@ -51,7 +48,7 @@ inline unsigned dense_blocks(const DensePlan &p)
         }
         longest = longest > n_x ? longest : n_x;
     }
-    return 8u * (unsigned)p.hg * longest;
+    return 8u * (unsigned)p.H * longest;
 }
 
 // grad_loc / grad_attn of bf16 box attention on a query grid (+ the combine step's workers, if any)
