@@ -818,7 +818,7 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
 // flavour of pointgrad2_kernel: buffered epilogue, one launch row)?
 // ------------------------------------------------- dense encoder kernels (boxattn_dense.h)
 #ifndef BOXATTN_DENSE_DEFAULT
-#define BOXATTN_DENSE_DEFAULT 0       // used without being asked for (boxattn_set_option(11, 2) switches them on)
+#define BOXATTN_DENSE_DEFAULT 1       // on unless boxattn_set_option(11, 1) switches them off
 #endif
 std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: per-point corner sums (boxattn_set_debug_buffer)
 // Encoder case: one query per pixel of packed levels, bf16 storage, C = 32, 2x2 points, <= 4 levels.
@@ -866,10 +866,7 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             w.ay = kDenseTile * ry; w.by = 0.5f * ry - 0.5f - my;
             const int pitch = cols + 2;             // slots of neighbouring rows start 2 bank groups apart
             const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots;
-            w.rows = fits ? rows : 0;
-            w.cols = fits ? cols : 0;
-            w.pitch = pitch;
-            w.off = used;
+            w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, pitch, used);
             if (fits) used += rows * pitch;
         }
     }

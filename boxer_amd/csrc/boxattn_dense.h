@@ -37,6 +37,9 @@ namespace boxattn {
 #ifndef BOXATTN_DENSE_DEBUG
 #define BOXATTN_DENSE_DEBUG 0     // 2: s_memtime stamps of every wave (tools/gpu_dense_trace.py, DensePlan::dbg)
 #endif
+#ifndef BOXATTN_DENSE_WPE
+#define BOXATTN_DENSE_WPE 4       // waves per SIMD the register allocation aims at (LDS allows 4 workgroups per CU)
+#endif
 typedef unsigned int dense_u32x4 __attribute__((ext_vector_type(4)));
 
 // n / d, n % d for 0 <= n < 2^24 (float estimate + correction), d > 0
@@ -79,40 +82,62 @@ __device__ __forceinline__ float dense_dot_row(const unsigned (&g)[16], const un
 // tile (the two 64-byte halves of a value line belong to neighbouring heads) -- its L2 then holds one
 // spatial band of the maps -- and walks the levels coarsest first, because the tiles of the coarse
 // levels are the slow ones (their fine-level points take the global path).
+//
+// All of it is scalar work at the top of every wave, and it used to be a third of a wave's life: the
+// plan lives in the kernel-argument segment, every field read is a scalar load, and reads behind a
+// branch or at a computed offset were issued one by one, each with its own wait (s_memtime stamps:
+// 6 600 of 17 700 cycles before the first row request left).  So: every statically addressed field
+// is read up front in straight-line code (one batch, one wait), the search over the levels is
+// branch-free, the query level's entry is selected from the registers, and the only reads at a
+// computed offset -- the L windows of the query level -- form one batch.
 struct DenseTileId {
     int lq;                  // query level, -1: no tile
     unsigned b;
     int ty, tx, h;
 };
+struct DenseMap { int H, W, start; };                   // what the kernel keeps of a level
+template <int L> struct DenseHot {
+    DenseMap lv[L];
+    int B, H, Lq, S;
+};
 template <int L>
-__device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, unsigned block)
+__device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, unsigned block,
+                                                           DenseHot<L> &hot, DenseMap &Q)
 {
+    DenseLevel lv[L];                                    // (the tile counts and reciprocals die with the decode)
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        lv[l] = pl.lv[l];
+        hot.lv[l] = DenseMap{lv[l].H, lv[l].W, lv[l].start};
+    }
+    hot.B = pl.B; hot.H = pl.H; hot.Lq = pl.Lq; hot.S = pl.S;
     DenseTileId t;
-    t.lq = -1;
     const unsigned x = block & 7u;
     unsigned j, h;
-    dense_divmod(block >> 3, pl.H, pl.rcp_h, j, h);
+    dense_divmod(block >> 3, hot.H, pl.rcp_h, j, h);
     t.h = (int)h;
-    unsigned ti = 0;
+    int lq = -1;
+    unsigned ti = 0, first = 0;
+    DenseLevel q = lv[0];
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
-        const unsigned n = (unsigned)pl.B * (unsigned)pl.lv[l].ntiles;
+        const unsigned n = (unsigned)hot.B * (unsigned)lv[l].ntiles;
         const unsigned lo = (x * n) >> 3, hi = ((x + 1) * n) >> 3;
-        const unsigned c = hi - lo;
-        if (t.lq < 0) {
-            if (j < c) {
-                t.lq = l;
-                ti = lo + j;
-            } else {
-                j -= c;
-            }
-        }
+        const bool here = j >= first && j < first + (hi - lo);
+        lq = here ? l : lq;
+        ti = here ? lo + (j - first) : ti;
+        q.H = here ? lv[l].H : q.H;           q.W = here ? lv[l].W : q.W;
+        q.start = here ? lv[l].start : q.start;
+        q.ntx = here ? lv[l].ntx : q.ntx;     q.ntiles = here ? lv[l].ntiles : q.ntiles;
+        q.rcp_ntx = here ? lv[l].rcp_ntx : q.rcp_ntx;
+        q.rcp_ntiles = here ? lv[l].rcp_ntiles : q.rcp_ntiles;
+        first += hi - lo;
     }
-    if (t.lq < 0) return t;
-    const DenseLevel &Q = pl.lv[t.lq];
+    t.lq = lq;
+    Q = DenseMap{q.H, q.W, q.start};
     unsigned tr, ty, tx;
-    dense_divmod(ti, Q.ntiles, Q.rcp_ntiles, t.b, tr);
-    dense_divmod(tr, Q.ntx, Q.rcp_ntx, ty, tx);
+    dense_divmod(ti, q.ntiles, q.rcp_ntiles, t.b, tr);
+    dense_divmod(tr, q.ntx, q.rcp_ntx, ty, tx);
     t.ty = (int)ty;
     t.tx = (int)tx;
     return t;
@@ -121,35 +146,43 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
 // Placement of a tile's windows (wave-uniform) and the cooperative fetch: wave w takes the window rows
 // w, w + 4, ... of every level; a row of up to 16 pixels x 64 bytes is one load instruction (4 lanes
 // per pixel).  Returns with the rows in LDS and the workgroup past its barrier.
-struct DenseWinPos { int rows, cols, pitch, off, x0, y0; };
+struct DenseWinPos {
+    unsigned geo;            // DenseWin::geo
+    int x0, y0;
+    __device__ __forceinline__ int rows() const { return (int)(geo & 31u); }
+    __device__ __forceinline__ int cols() const { return (int)((geo >> 5) & 31u); }
+    __device__ __forceinline__ int pitch() const { return (int)((geo >> 10) & 63u); }
+    __device__ __forceinline__ int off() const { return (int)(geo >> 16); }
+};
 
 template <int L> struct DenseStageRegs { dense_u32x4 reg[L][kDenseWinMax / 4]; };
 
 template <int L>
-__device__ __forceinline__ void dense_stage_issue(const DensePlan &pl, const DenseTileId &t, int lane,
-                                                  int wv, __amdgpu_buffer_rsrc_t rs, DenseWinPos (&win)[L],
+__device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const DenseWin (&wrow)[L],
+                                                  const DenseTileId &t, int lane, int wv,
+                                                  __amdgpu_buffer_rsrc_t rs, DenseWinPos (&win)[L],
                                                   DenseStageRegs<L> &st)
 {
     constexpr int C = 32, RPW = kDenseWinMax / 4;              // rows per wave and level at most
     const int j = lane >> 2, chunk = lane & 3;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        const DenseLevel T = pl.lv[l];
-        const DenseWin w = pl.win[t.lq][l];
+        const DenseMap T = hot.lv[l];
+        const DenseWin w = wrow[l];
         DenseWinPos &o = win[l];
-        o.rows = w.rows; o.cols = w.cols; o.pitch = w.pitch; o.off = w.off;
+        o.geo = w.geo;
         const int x0 = (int)floorf((float)t.tx * w.ax + w.bx), y0 = (int)floorf((float)t.ty * w.ay + w.by);
-        o.x0 = __builtin_amdgcn_readfirstlane(max(0, min(x0, T.W - w.cols)));
-        o.y0 = __builtin_amdgcn_readfirstlane(max(0, min(y0, T.H - w.rows)));
+        o.x0 = __builtin_amdgcn_readfirstlane(max(0, min(x0, T.W - o.cols())));
+        o.y0 = __builtin_amdgcn_readfirstlane(max(0, min(y0, T.H - o.rows())));
         const int jx = min(o.x0 + j, T.W - 1);
         const unsigned voff =
-            ((((t.b * (unsigned)pl.S + (unsigned)(T.start + jx)) * (unsigned)pl.H + (unsigned)t.h) * C) +
+            ((((t.b * (unsigned)hot.S + (unsigned)(T.start + jx)) * (unsigned)hot.H + (unsigned)t.h) * C) +
              (unsigned)chunk * 8u) * 2u;
-        const unsigned row_bytes = (unsigned)T.W * (unsigned)pl.H * (C * 2u);
+        const unsigned row_bytes = (unsigned)T.W * (unsigned)hot.H * (C * 2u);
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             const int r = wv + 4 * k;
-            if (r < o.rows) {                                          // wave-uniform
+            if (r < o.rows()) {                                        // wave-uniform
                 const unsigned soff = (unsigned)min(o.y0 + r, T.H - 1) * row_bytes;
                 st.reg[l][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
             }
@@ -166,55 +199,104 @@ __device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned ch
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const DenseWinPos &o = win[l];
-        unsigned char *dst = lds + __mul24(o.off + j, kDenseSlotBytes) + chunk * 16;
+        unsigned char *dst = lds + __mul24(o.off() + j, kDenseSlotBytes) + chunk * 16;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             const int r = wv + 4 * k;
-            if (r < o.rows && j < o.cols)
-                *reinterpret_cast<dense_u32x4 *>(dst + __mul24(r * o.pitch, kDenseSlotBytes)) = st.reg[l][k];
+            if (r < o.rows() && j < o.cols())
+                *reinterpret_cast<dense_u32x4 *>(dst + __mul24(r * o.pitch(), kDenseSlotBytes)) = st.reg[l][k];
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ unsigned quad_bcast_u32(unsigned v, int t)      // t is a constant after unrolling
+{
+    switch (t & 3) {
+    case 0: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
+    case 1: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true);
+    case 2: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+    default: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
+    }
 }
 
 // The four corner sums S_k = sum_c g_c v_k,c of one sample point: from the staged window where its
 // footprint lies inside, else from global memory (`slow`, decided per lane, entered per wave).
 __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const DenseWinPos &o,
                                                   const unsigned char *lds, const unsigned (&gw)[16],
-                                                  const bf16_t *value, size_t row0, int H, int h, bool vq,
-                                                  float (&sk)[4])
+                                                  const bf16_t *value, unsigned row0, int H, int h, bool vq,
+                                                  int lane_p, float (&sk)[4])
 {
     constexpr int C = 32;
+    const int rows = o.rows(), cols = o.cols();
     const int r0 = s.y0 - o.y0, c0 = s.x0 - o.x0;                  // window coordinates of corner 1
-    const bool in_r0 = r0 >= 0 && r0 < o.rows, in_r1 = r0 + 1 >= 0 && r0 + 1 < o.rows;
-    const bool in_c0 = c0 >= 0 && c0 < o.cols, in_c1 = c0 + 1 >= 0 && c0 + 1 < o.cols;
+    const bool in_r0 = r0 >= 0 && r0 < rows, in_r1 = r0 + 1 >= 0 && r0 + 1 < rows;
+    const bool in_c0 = c0 >= 0 && c0 < cols, in_c1 = c0 + 1 >= 0 && c0 + 1 < cols;
     const bool in[4] = {in_r0 && in_c0, in_r0 && in_c1, in_r1 && in_c0, in_r1 && in_c1};
     const bool slow = vq && ((s.ok[0] && !in[0]) || (s.ok[1] && !in[1]) || (s.ok[2] && !in[2]) ||
                              (s.ok[3] && !in[3]));
-    if (o.rows > 0) {                                              // wave-uniform
-        const int rr0 = min(max(r0, 0), o.rows - 1), rr1 = min(max(r0 + 1, 0), o.rows - 1);
-        const int cc0 = min(max(c0, 0), o.cols - 1), cc1 = min(max(c0 + 1, 0), o.cols - 1);
-        const int row0s = o.off + __mul24(rr0, o.pitch), row1s = o.off + __mul24(rr1, o.pitch);
+    const bool hit = vq && ((s.ok[0] && in[0]) || (s.ok[1] && in[1]) || (s.ok[2] && in[2]) || (s.ok[3] && in[3]));
+    if (rows > 0 && __builtin_amdgcn_ballot_w64(hit) != 0ull) {    // wave-uniform: some corner is staged
+        const int rr0 = min(max(r0, 0), rows - 1), rr1 = min(max(r0 + 1, 0), rows - 1);
+        const int cc0 = min(max(c0, 0), cols - 1), cc1 = min(max(c0 + 1, 0), cols - 1);
+        const int row0s = o.off() + __mul24(rr0, o.pitch()), row1s = o.off() + __mul24(rr1, o.pitch());
         const int slot[4] = {row0s + cc0, row0s + cc1, row1s + cc0, row1s + cc1};
+        // two corners at a time: 8 LDS reads in flight, then the 32 dot products; the rows of corners
+        // that do not count (outside the map or the window) are read from a clamped slot and masked
+        // out bitwise -- a select on the finished sum lets the compiler put every corner under its own
+        // branch (reads, wait, dots, four times in a row), a multiplication by 0 would let a non-finite
+        // value of an unrelated pixel through
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            unsigned vw[16];
-            dense_load_row(lds + __mul24(slot[k], kDenseSlotBytes), vw);
-            const float d = dense_dot_row(gw, vw);
-            sk[k] = (s.ok[k] && in[k]) ? d : 0.f;
+        for (int k0 = 0; k0 < 4; k0 += 2) {
+            unsigned va[16], vb[16];
+            dense_load_row(lds + __mul24(slot[k0], kDenseSlotBytes), va);
+            dense_load_row(lds + __mul24(slot[k0 + 1], kDenseSlotBytes), vb);
+            const float da = dense_dot_row(gw, va), db = dense_dot_row(gw, vb);
+            sk[k0] = __uint_as_float(__float_as_uint(da) & ((s.ok[k0] && in[k0]) ? 0xffffffffu : 0u));
+            sk[k0 + 1] = __uint_as_float(__float_as_uint(db) & ((s.ok[k0 + 1] && in[k0 + 1]) ? 0xffffffffu : 0u));
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) sk[k] = 0.f;
     }
     if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {               // wave-uniform
-        if (slow) {
+        // The global path, one point of every quad at a time (a quad = the 4 points of one query): the
+        // quad's lanes fetch the four corner rows of point t together, 16 bytes each -- one 64-byte
+        // request per row, as the gather kernels do it; a lane fetching whole rows alone costs the
+        // vector L1 four requests per row -- and sum their partial dot products with DPP adds.
+        const int p = lane_p;
+        unsigned gch[4];                                           // this lane's 8 channels of the grad_out row
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gch[i] = p == 0 ? gw[i] : p == 1 ? gw[4 + i] : p == 2 ? gw[8 + i] : gw[12 + i];
+        unsigned off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            off[k] = (unsigned)(((row0 + (unsigned)s.pix[k]) * H + h) * (C * 2)) + (unsigned)p * 16u;
+        const unsigned okm = (s.ok[0] ? 1u : 0u) | (s.ok[1] ? 2u : 0u) | (s.ok[2] ? 4u : 0u) | (s.ok[3] ? 8u : 0u) |
+                             (slow ? 16u : 0u);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned m_t = quad_bcast_u32(okm, t);
+            if (__builtin_amdgcn_ballot_w64((m_t & 16u) != 0u) == 0ull) continue;      // wave-uniform
+            float part[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                unsigned vw[16];
-                dense_load_row(value + ((row0 + (unsigned)s.pix[k]) * H + h) * C, vw);
-                const float d = dense_dot_row(gw, vw);
-                sk[k] = s.ok[k] ? d : 0.f;
+                // (my own offset already carries my chunk: take lane t's row, keep my 16-byte piece)
+                const unsigned o = quad_bcast_u32(off[k] - (unsigned)p * 16u, t) + (unsigned)p * 16u;
+                dense_u32x4 v = {0u, 0u, 0u, 0u};
+                if (m_t & 16u) v = *reinterpret_cast<const dense_u32x4 *>(reinterpret_cast<const char *>(value) + o);
+                const unsigned vw[4] = {v.x, v.y, v.z, v.w};
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gch[i]),
+                                                        __builtin_bit_cast(bf16x2_t, vw[i]), d, false);
+                part[k] = group_sum<4>(d);
+            }
+            if (p == t && slow) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sk[k] = s.ok[k] ? part[k] : 0.f;
             }
         }
     }
@@ -223,7 +305,7 @@ __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const 
 constexpr int kDenseResFloats = 16 * 16 * 3;       // per wave: the results of 16 queries x 16 points
 
 template <int L>
-__global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
+__global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
     const bf16_t *__restrict__ grad_out, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
     DensePlan pl, unsigned value_bytes, unsigned tile_blocks, CombineTail ct)
@@ -231,7 +313,10 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
     constexpr int C = 32, P = 4, LP = L * P;
     __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
     static_assert(4 * kDenseResFloats * sizeof(float) <= sizeof(win_lds), "the result tiles reuse the window buffer");
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    // (the wave index as a scalar: everything per window row -- row index, clamps, byte offsets, the
+    // "row exists" branches -- is then scalar code; derived from threadIdx in a vector register it was
+    // ~25 vector instructions, a v_readfirstlane and an exec-mask branch per row)
+    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     if (blockIdx.x >= tile_blocks) {                  // the appended combine workgroups (pointgrad2_kernel)
         if (ct.workers > 0) {
             const int w = (int)((blockIdx.x - tile_blocks) * 4 + wv);
@@ -244,18 +329,23 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
         return;
     }
 #if BOXATTN_DENSE_DEBUG == 2
-    unsigned long long ts[8];
+    unsigned long long ts[12];
     int ts_n = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, the same on every XCD
 #define DENSE_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts[ts_n++] = __builtin_amdgcn_s_memtime(); \
                            __builtin_amdgcn_sched_barrier(0); } while (0)
     DENSE_STAMP();
 #else
 #define DENSE_STAMP() do { } while (0)
 #endif
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x);
+    DenseHot<L> hot;
+    DenseMap Q;
+    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q);
     if (t.lq < 0) return;                                          // workgroup-uniform
-    const int H = pl.H, h = t.h;
-    const DenseLevel Q = pl.lv[t.lq];
+    DenseWin wrow[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) wrow[l] = pl.win[t.lq][l];
+    const int H = hot.H, h = t.h;
 
     // ---- lane -> (query of the wave's 4x4 sub-tile, point)
     const int qi = lane >> 2, p = lane & 3;
@@ -263,7 +353,7 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
     const int qx = t.tx * kDenseTile + (wv & 1) * kDenseSub + (qi & 3);
     const bool vq = qy < Q.H && qx < Q.W;
     const unsigned q = (unsigned)(Q.start + min(qy, Q.H - 1) * Q.W + min(qx, Q.W - 1));
-    const unsigned qh = (t.b * (unsigned)pl.Lq + q) * (unsigned)H + (unsigned)h;
+    const unsigned qh = (t.b * (unsigned)hot.Lq + q) * (unsigned)H + (unsigned)h;
     const unsigned pt0 = qh * (unsigned)LP;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     const __amdgpu_buffer_rsrc_t rs =
@@ -272,7 +362,9 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
     // (locations, weights, grad_out row) are requested behind them and land while the rows are staged
     DenseWinPos win[L];
     DenseStageRegs<L> stage;
-    dense_stage_issue<L>(pl, t, lane, wv, rs, win, stage);
+    DENSE_STAMP();                                                 // tile decoded
+    dense_stage_issue<L>(hot, wrow, t, lane, wv, rs, win, stage);
+    DENSE_STAMP();                                                 // window rows requested
     float2 xy[L];
     float a[L];
 #pragma unroll
@@ -282,16 +374,21 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
     }
     unsigned gw[16];                                               // the query's grad_out row
     dense_load_row(grad_out + (size_t)qh * C, gw);
+    DENSE_STAMP();                                                 // own inputs requested
+#if BOXATTN_DENSE_DEBUG == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DENSE_STAMP();                                                 // everything has arrived
+#endif
     dense_stage_commit<L>(lane, wv, win_lds, win, stage);
     DENSE_STAMP();
 
     float ga[L], gx[L], gy[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        const DenseLevel T = pl.lv[l];
+        const DenseMap T = hot.lv[l];
         const Sample<float> s = locate<float>(xy[l].x, xy[l].y, T.H, T.W);
         float sk[4];
-        dense_corner_sums(s, win[l], win_lds, gw, value, (size_t)t.b * pl.S + T.start, H, h, vq, sk);
+        dense_corner_sums(s, win[l], win_lds, gw, value, t.b * (unsigned)hot.S + (unsigned)T.start, H, h, vq, p, sk);
         const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
         const float gs_ = w1 * sk[0] + w2 * sk[1] + w3 * sk[2] + w4 * sk[3];
         const float gx_ = (float)T.W * a[l] * (s.hh * (sk[1] - sk[0]) + s.lh * (sk[3] - sk[2]));
@@ -331,6 +428,8 @@ __global__ __launch_bounds__(256, 4) void pointgrad_dense_kernel(
         o[1] = (float)(unsigned)(ts[0] & 0xffffffu);
         for (int i = 1; i < ts_n; ++i) o[1 + i] = (float)(unsigned)(ts[i] - ts[0]);
         o[19] = (float)ts_n;
+        o[17] = (float)(unsigned)(rt0 & 0xffffffu);
+        o[18] = (float)(unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffffu);
     }
 #endif
 }

@@ -26,8 +26,12 @@ struct DenseLevel {
 // Staged pixel (r, c) of the window lives in slot off + r * pitch + c.
 struct DenseWin {
     float ax, bx, ay, by;
-    int rows, cols, pitch, off;
+    unsigned geo;            // rows | cols << 5 | pitch << 10 | off << 16 (one scalar register, see dense_win_*)
 };
+inline unsigned dense_win_pack(int rows, int cols, int pitch, int off)
+{
+    return (unsigned)rows | ((unsigned)cols << 5) | ((unsigned)pitch << 10) | ((unsigned)off << 16);
+}
 struct DensePlan {
     int L, B, Lq, S, H;
     float rcp_h;

@@ -27,7 +27,7 @@ fn(None)
 d = dbg.view(-1, 20).cpu().numpy()
 d = d[d[:, 19] > 0]
 print("waves traced:", len(d))
-names = ["decode+loads+staging+barrier", "levels", "epilogue+stores"]
+names = ["decode", "issue rows", "issue own loads", "wait data", "lds writes+barrier", "levels", "epilogue+stores"]
 for lq in range(4):
     w = d[d[:, 0] == lq]
     if not len(w):
@@ -37,5 +37,17 @@ for lq in range(4):
     dt = np.diff(np.concatenate([np.zeros((len(w), 1)), ts], axis=1), axis=1)
     print("lq %d: %5d waves, life %7.0f cycles (min %d max %d)" % (lq, len(w), ts[:, -1].mean(), ts[:, -1].min(), ts[:, -1].max()))
     print("   " + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, dt.mean(0))))
-start = d[:, 1]
-print("kernel span (cycles, 24-bit wrap ignored):", (start.max() - start.min()), "last end", (start + d[np.arange(len(d)), 1 + d[:, 19].astype(int) - 1]).max() - start.min())
+start = d[:, 17].astype(np.int64)          # s_memrealtime, 10 ns ticks
+end = d[:, 18].astype(np.int64)
+t0 = start.min()
+rel_s, rel_e = (start - t0) / 100.0, (end - t0) / 100.0          # us
+print("wave starts (us): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(rel_s, [10, 50, 90, 99, 100])))
+print("wave ends   (us): p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(rel_e, [10, 50, 90, 99, 100])))
+for lq in range(4):
+    m = d[:, 0] == lq
+    if m.any():
+        print("  lq %d: starts p1 %.1f p50 %.1f p99 %.1f | ends p50 %.1f p99 %.1f max %.1f | life p50 %.1f us" % (
+            (lq,) + tuple(np.percentile(rel_s[m], [1, 50, 99])) + tuple(np.percentile(rel_e[m], [50, 99, 100])) +
+            (np.median(rel_e[m] - rel_s[m]),)))
+edges = np.linspace(0, rel_e.max(), 31)
+print("waves in flight every %.1f us:" % (edges[1] - edges[0]), [int(((rel_s <= t) & (rel_e > t)).sum()) for t in edges])
