@@ -39,6 +39,7 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptDense = 11,        // dense (matrix-core) encoder kernels: 0 default (BOXATTN_DENSE_DEFAULT), 1 off, 2 on
        kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
+       kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
        kNumOpts = 16 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
@@ -648,7 +649,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
     size_t n_items;
-    size_t part, subtot, offsets, items, combos, records, partials, scan_tmp, total;
+    size_t part, subtot, offsets, items, combos, records, partials, scan_tmp, cursor, total;
     int q_per_wg, n_wg;                                     // launch geometry of the bin passes
 };
 
@@ -727,7 +728,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
     w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
     size_t o = 0;
     w.n_items = o; o += align_up(ns * 2 * 4);
-    w.part = o;    o += align_up(ns * w.n_wg * (size_t)p.nblk * 4);
+    w.part = o;    o += align_up(ns * std::max(w.n_wg, kDenseGroups) * (size_t)p.nblk * 4);
     w.subtot = o;  o += align_up(ns * kScanSub * (size_t)p.nblk * 4);
     w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
     w.items = o;   o += align_up(ns * p.item_cap * 16);
@@ -738,6 +739,10 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
     // inside a segment + the segments' totals
     w.scan_tmp = o;
     if (p.nblk > kScanThreads) o += align_up(ns * ((size_t)p.nblk + kMaxBlocks / kScanThreads) * 16);
+    // window-staged kernels as the binning passes (bf16 box attention, encoder): their groups' counts use
+    // the first kDenseGroups workgroup rows of `part`; one cursor per (slice, group, block) on top
+    w.cursor = o;
+    if (wide && p.nblk <= kDenseFillMaxBlocks) o += align_up(ns * kDenseGroups * (size_t)p.nblk * 4);
     w.total = o;
     return w;
 }
@@ -882,11 +887,45 @@ inline bool dense_pointgrad_ok(const DensePlan *dp, const void *value, const voi
 
 inline void run_pointgrad_dense(const bf16_t *value, const float *loc, const float *attn,
                                 const bf16_t *grad_out, const Dims &d, const DensePlan &dp,
-                                float *grad_loc, float *grad_attn, hipStream_t st, const CombineTail *ct)
+                                float *grad_loc, float *grad_attn, hipStream_t st, const CombineTail *ct,
+                                const DenseBin *bin = nullptr)
 {
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
     launch_pointgrad_dense(value, loc, attn, grad_out, dp, grad_loc, grad_attn,
-                           (unsigned)(d.n_value() * sizeof(bf16_t)), st, ct ? *ct : CombineTail{});
+                           (unsigned)(d.n_value() * sizeof(bf16_t)), st, ct ? *ct : CombineTail{},
+                           bin ? *bin : DenseBin{});
+}
+
+static_assert(kDenseScanSub == kScanSub, "the window-staged fill reads the scan's sub-range tables");
+// May the window-staged kernels do the binning (count + records) of this plan?
+inline bool dense_fill_ok(const DensePlan *dp, const BinPlan &plan)
+{
+    // (opt-in: measured at C2 bf16 as fast as the two bin_kernel passes, not faster -- count 17 us + scan 10
+    // + 26 us on top of the point-gradient kernel + 6 us for the combine step's own launch against
+    // 12 + 12 + 23)
+    return dp && opt(kOptDenseFill) == 2 && plan.nblk <= kDenseFillMaxBlocks && plan.nblk <= kScanThreads &&
+           plan.L <= kDenseMaxLevels;
+}
+
+// Count + scan of the binned backward by the window-staged count kernel: counts[slice][group][block]
+// through one global atomic per (workgroup, touched block) into the (zeroed) first kDenseGroups workgroup
+// rows of `part`, then the block scan in its few-bin-workgroups form.  The records themselves are
+// written by the point-gradient kernel of the backward (cursors: one per (slice, group, block), zeroed
+// here).
+inline void launch_dense_binning(const float *loc, const Dims &d, const BinPlan &plan, const WsLayout &w,
+                                 char *ws, const DensePlan &dp, hipStream_t st)
+{
+    ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);
+    const int ns = d.B * d.H;
+    int *part = (int *)(ws + w.part), *subtot = (int *)(ws + w.subtot);
+    int *n_items = (int *)(ws + w.n_items), *offsets = (int *)(ws + w.offsets);
+    int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
+    const size_t gbytes = (size_t)ns * kDenseGroups * plan.nblk * sizeof(int);
+    hipMemsetAsync(part, 0, gbytes, st);
+    hipMemsetAsync(ws + w.cursor, 0, gbytes, st);
+    launch_dense_count(loc, dp, dense_bin(plan, part, nullptr, nullptr, nullptr, nullptr), st);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items, combos,
+                       n_items, plan, part, kDenseGroups);
 }
 
 template <typename ST>
@@ -983,18 +1022,44 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
     }
 }
 
+#define BOXATTN_TUNE_ACC_WG_CAP_DEFAULT 1024     // accumulate workgroups per slice at most (see BOXATTN_TUNE_ACC_WG_CAP)
 template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
                float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st,
-               const GridSrc *gs = nullptr, const DensePlan *dp = nullptr)
+               const GridSrc *gs = nullptr, const DensePlan *dp = nullptr, int dense_fill = 0)
 {
+    // dense_fill: 0 no; 1 the window-staged kernels bin (count + scan here, records by the point-gradient
+    // kernel); 2 the same, counted and scanned already (by the training forward)
     const int ns = d.B * d.H;
     int *n_items = (int *)(ws + w.n_items);
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     float *partials = (float *)(ws + w.partials);
+    if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
+        if (dense_fill && dp) {
+            // [count, scan] -> point gradients + records -> accumulate -> combine
+            if (dense_fill == 1) launch_dense_binning(loc, d, plan, w, ws, *dp, st);
+            const DenseBin bin = dense_bin(plan, (int *)(ws + w.part), (const int *)(ws + w.subtot), offsets,
+                                           (int *)(ws + w.cursor), records);
+            run_pointgrad_dense(value, loc, w_sp, grad_out, d, *dp, grad_loc, grad_sp, st, nullptr, &bin);
+            const int ns8 = (ns + 7) / 8 * 8;
+            const int wg_per_slice = std::min(BOXATTN_TUNE_ACC_WG_CAP_DEFAULT, std::max(1, plan.item_cap));
+            {
+                ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
+                hipLaunchKernelGGL((binned_accumulate_mfma_kernel<ST, 4 * G>), dim3(wg_per_slice, ns8),
+                                   dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
+                                   records, grad_value, partials);
+            }
+            {
+                ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
+                hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
+                                   n_items, partials, combine_plan(plan), d.S, d.H, grad_value);
+            }
+            return finish();
+        }
+    }
     // grad_loc / grad_weight (query-major gathers) do not depend on the binning: where it pays
     // (side_stream_worth) they are launched on the library's helper stream, next to the bin
     // passes and the accumulate kernel.  Fork/join with events, so the caller still sees one
@@ -1231,7 +1296,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         }
         if (plan_kind == 2) plan_kind = 0;     // boxes in the workspace, but the binned path runs
     }
-    const bool plan_ready = plan_kind == 1;
+    const bool plan_ready = plan_kind == 1;      // (kind 3 -- counted by the window-staged kernels -- see below)
     WsLayout w{};
     if (binned) {
         w = ws_layout(d, plan, wide_workspace(kBf16, d));
@@ -1261,12 +1326,18 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     int rc = 0;
     DensePlan dense;
     const DensePlan *dp = kBf16 && !INST && make_dense_plan(d, shapes_host, lsi_host, dense) ? &dense : nullptr;
+    // the window-staged kernels as the binning passes: whenever they compute the point gradients and the
+    // matrix-core accumulate reads wide records (a forward-built classic plan, kind 1, is used as it is)
+    int dense_fill = 0;
+    if (!gs && plan_kind != 1 && dense_fill_ok(dp, plan) && mfma_accumulate<ST, INST>(d) &&
+        dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp))
+        dense_fill = plan_kind == 3 ? 2 : 1;
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
-                                      plan_ready, st, gs, dp);                                  \
+                                      plan_ready, st, gs, dp, dense_fill);                      \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -1312,6 +1383,17 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
                 if (rc == 0 && plan_built) *plan_built = 2;
                 return rc;
             }
+        }
+    }
+    if constexpr (std::is_same<ST, bf16_t>::value && !INST) {      // window-staged kernels: count + scan only
+        DensePlan dense;
+        if (make_dense_plan(d, shapes_host, lsi_host, dense) && dense_fill_ok(&dense, plan) &&
+            mfma_accumulate<ST, INST>(d) && aligned(loc, 8)) {
+            launch_dense_binning(loc, d, plan, w, (char *)workspace, dense, st);
+            const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                                shapes_host, lsi_host);
+            if (rc == 0 && plan_built) *plan_built = 3;
+            return rc;
         }
     }
     SideStream side(st, side_stream_worth<ST>(d));

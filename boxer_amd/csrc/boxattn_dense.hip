@@ -4,18 +4,38 @@
 
 namespace boxattn {
 
+void launch_dense_count(const float *loc, const DensePlan &dp, const DenseBin &bin, hipStream_t st)
+{
+    const unsigned blocks = dense_blocks(dp);
+    const size_t lds = (size_t)bin.nblk * sizeof(int);
+#define BOXATTN_DENSE_CNT(LV_)                                                                      \
+    case LV_:                                                                                       \
+        hipLaunchKernelGGL((dense_count_kernel<LV_>), dim3(blocks), dim3(256), lds, st, loc, dp, bin); \
+        break;
+    switch (dp.L) {
+        BOXATTN_DENSE_CNT(1) BOXATTN_DENSE_CNT(2) BOXATTN_DENSE_CNT(3) BOXATTN_DENSE_CNT(4)
+    }
+#undef BOXATTN_DENSE_CNT
+}
+
 void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float *attn,
                             const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
                             float *grad_attn, unsigned value_bytes, hipStream_t st,
-                            const CombineTail &tail)
+                            const CombineTail &tail, const DenseBin &bin)
 {
     const unsigned tail_blocks = tail.workers > 0 ? (unsigned)(tail.workers * tail.plan.n_slices + 3) / 4 : 0;
     const unsigned blocks = dense_blocks(dp);
+    const size_t lds = bin.on ? (size_t)bin.nblk * sizeof(int) : 0;
 #define BOXATTN_DENSE_PG(LV_)                                                                           \
     case LV_:                                                                                           \
-        hipLaunchKernelGGL((pointgrad_dense_kernel<LV_>), dim3(blocks + tail_blocks), dim3(256), 0, st, \
-                           value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes, blocks,    \
-                           tail);                                                                       \
+        if (bin.on)                                                                                     \
+            hipLaunchKernelGGL((pointgrad_dense_kernel<LV_, true>), dim3(blocks + tail_blocks), dim3(256), lds, \
+                               st, value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes,   \
+                               blocks, tail, bin);                                                      \
+        else                                                                                            \
+            hipLaunchKernelGGL((pointgrad_dense_kernel<LV_, false>), dim3(blocks + tail_blocks), dim3(256), 0, \
+                               st, value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes,   \
+                               blocks, tail, bin);                                                      \
         break;
     switch (dp.L) {
         BOXATTN_DENSE_PG(1) BOXATTN_DENSE_PG(2) BOXATTN_DENSE_PG(3) BOXATTN_DENSE_PG(4)

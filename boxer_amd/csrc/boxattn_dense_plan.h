@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "boxattn_combine.h"
+#include "boxattn_binplan.h"
 
 namespace boxattn {
 
@@ -55,10 +56,50 @@ inline unsigned dense_blocks(const DensePlan &p)
     return 8u * (unsigned)p.H * longest;
 }
 
-// grad_loc / grad_attn of bf16 box attention on a query grid (+ the combine step's workers, if any)
+// The bin records of the destination-binned backward (boxattn_binned.h), counted and written by
+// these kernels' workgroups instead of the two bin_kernel passes: a workgroup's points are counted /
+// ranked in an LDS table over the slice's blocks and handed to the bins with ONE global atomic per
+// touched block -- `count`: += into counts[slice][block] (zeroed by the caller; bin_scan_kernel turns
+// them into `offsets` and leaves zeros behind), `fill`: cursor[slice][block] += n, returning the
+// workgroup's first slot.  Exact for any input; the record order inside a bin follows the atomics.
+// Every tile of a slice has points in the few blocks of the coarse levels: one counter per block would
+// take a slice's 238 workgroups (C2) one after the other -- same-address device atomics, measured
+// 17 us for the count pass alone.  So the workgroups are spread over kDenseGroups groups (tile index
+// mod 16) that play the part of the bin_kernel's workgroups: counts / first slots / cursors per
+// (slice, group, block), the scan kernels' two-level prefix over the groups as it is.
+constexpr int kDenseFillMaxBlocks = 1024;      // blocks per slice the LDS table is built for (4 per thread)
+constexpr int kDenseGroups = 16;
+constexpr int kDenseScanSub = 8;               // = kScanSub of boxattn_binned.h (sub-ranges of bin workgroups in the scan)
+struct DenseBinLevel { unsigned mw, mh; int blk0; };      // what blk_of() needs beyond the map size (BinLevel)
+struct DenseBin {
+    int nblk, rec_cap, lp_bits;    // BinPlan
+    DenseBinLevel lv[kDenseMaxLevels];
+    int *part;               // [slice][group][nblk]: count: += (zeroed by the caller); fill: first slot in the sub-range
+    const int *subtot;       // [slice][kScanSub][nblk] first slot of the group's sub-range in the bin (scan)
+    const int *offsets;      // [slice][nblk + 1] first record of every bin (scan)
+    int *cursor;             // [slice][group][nblk] zeros on entry (fill)
+    int *records;            // wide records {id, x, y, weight}, rec_cap per slice
+    int on;
+};
+inline DenseBin dense_bin(const BinPlan &bp, int *part, const int *subtot, const int *offsets, int *cursor,
+                          int *records)
+{
+    DenseBin b{};
+    b.nblk = bp.nblk; b.rec_cap = bp.rec_cap; b.lp_bits = bp.lp_bits;
+    for (int l = 0; l < kDenseMaxLevels && l < bp.L; ++l) b.lv[l] = DenseBinLevel{bp.lv[l].mw, bp.lv[l].mh, bp.lv[l].blk0};
+    b.part = part; b.subtot = subtot; b.offsets = offsets; b.cursor = cursor; b.records = records;
+    b.on = 1;
+    return b;
+}
+
+// bin.part[slice][group][block] += records of every block (zeroed by the caller)
+void launch_dense_count(const float *loc, const DensePlan &dp, const DenseBin &bin, hipStream_t st);
+
+// grad_loc / grad_attn of bf16 box attention on a query grid (+ the combine step's workers, if any;
+// + the bin records if bin.on)
 void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float *attn,
                             const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
                             float *grad_attn, unsigned value_bytes, hipStream_t st,
-                            const CombineTail &tail);
+                            const CombineTail &tail, const DenseBin &bin);
 
 }  // namespace boxattn

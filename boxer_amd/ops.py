@@ -96,7 +96,8 @@ class BackwardPlan:
     __slots__ = ("ws", "key", "kind")
 
     def __init__(self, ws, key, kind=1):
-        # kind: 1 = binning plan, 2 = query-grid tile boxes (what *_fwd_train_* reported)
+        # kind: 1 = binning plan, 2 = query-grid tile boxes, 3 = counted bins whose records the
+        # backward writes (what *_fwd_train_* reported)
         self.ws, self.key, self.kind = ws, key, kind
 
 

@@ -139,7 +139,9 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * plan_ready: 0 = the call prepares everything itself; otherwise the value a *_fwd_train_* call
  * returned in *plan_built for the SAME sampling locations and dimensions -- 1: `workspace` holds
  * the binning plan, 2: it holds the query-grid tile boxes (bf16 box attention in the encoder
- * case, Lq == S: no global binning at all).  A plan the backward cannot use
+ * case, Lq == S: no global binning at all), 3: it holds the counted and
+ * scanned bins whose records the backward's point-gradient kernel writes itself (bf16 box attention
+ * in the encoder case, window-staged kernels).  A plan the backward cannot use
  * (operands the fast paths reject) is ignored and the call falls back.
  * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`; with
  * boxattn_set_variant(6) the point-gradient kernel runs on a library-owned low-priority helper
@@ -210,8 +212,9 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * bf16 box flavour, whose 16-byte records carry them, the attention weights -- ahead of the
  * forward kernel (variant 6: on the library's helper stream, next to it) into `workspace`
  * (boxattn_bwd_workspace_bytes bytes; it must stay untouched until the matching *_bwd_ws_*
- * call, which is then given plan_ready = 1).  *plan_built is set to 1 if the plan was built,
- * 0 if the call was just a plain forward (shape not eligible / workspace too small).
+ * call, which is then given plan_ready = *plan_built).  *plan_built is set to the kind of plan
+ * that was built (1, 2 or 3, see above), 0 if the call was just a plain forward (shape not eligible /
+ * workspace too small).
  */
 int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                           const float *loc, const float *attn, int B, int S, int H, int C, int L,

@@ -16,6 +16,7 @@ import bench
 pytestmark = pytest.mark.gpu
 
 OPT_DENSE = 11          # boxattn_set_option key: 0 library default, 1 dense kernels off, 2 on
+OPT_DENSE_FILL = 14     # ... the window-staged kernels also count and write the bin records: 2 on (default off)
 
 
 def _lib():
@@ -30,6 +31,16 @@ def dense_switch():
     old = lib.boxattn_set_option(OPT_DENSE, 0)
     yield lambda on: lib.boxattn_set_option(OPT_DENSE, 2 if on else 1)
     lib.boxattn_set_option(OPT_DENSE, old)
+
+
+@pytest.fixture(params=[False, True], ids=["bin_kernel", "own_binning"])
+def binning(request):
+    """Both ways of binning under the window-staged point gradients: the two bin_kernel passes (default)
+    and count / records by the window-staged kernels themselves (atomic cursors per block and group)."""
+    lib = _lib()
+    old = lib.boxattn_set_option(OPT_DENSE_FILL, 2 if request.param else 0)
+    yield request.param
+    lib.boxattn_set_option(OPT_DENSE_FILL, old)
 
 
 def make_case(levels, family, H=8, B=2, seed=0):
@@ -81,7 +92,7 @@ LEVELS = {
 
 @pytest.mark.parametrize("family", ["model", "test", "mixed", "border"])
 @pytest.mark.parametrize("lv", sorted(LEVELS))
-def test_dense_kernels_match_oracle(lv, family, dense_switch):
+def test_dense_kernels_match_oracle(lv, family, dense_switch, binning):
     dense_switch(True)
     inp = make_case(LEVELS[lv], family)
     out, grads = run(inp)
@@ -90,7 +101,7 @@ def test_dense_kernels_match_oracle(lv, family, dense_switch):
 
 
 @pytest.mark.parametrize("H", [1, 4, 6, 8])
-def test_dense_kernels_head_counts(H, dense_switch):
+def test_dense_kernels_head_counts(H, dense_switch, binning):
     dense_switch(True)
     inp = make_case(LEVELS["4lv"], "mixed", H=H, B=1, seed=3)
     out, grads = run(inp, with_plan=False)

@@ -1080,7 +1080,12 @@ def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, 
     gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, grid, attn, gout, 64)
     go, rows = ops.box_grid_backward(ref, off, kidx, vr, angle_mode, gl, need_ref_grad=True)
     torch.cuda.synchronize()
-    assert torch.equal(fused[3], ga)
+    if dtype == torch.bfloat16:
+        # bf16 encoder shapes: box_attn_backward takes the window-staged point-gradient kernel, the
+        # fused entry point the gather kernel -- same products, another order of the 32-term sums
+        assert (fused[3] - ga).abs().max().item() <= 2e-5 * max(1.0, ga.abs().max().item())
+    else:
+        assert torch.equal(fused[3], ga)
     # (grad_value: same kernels, but the summation order inside a bin differs from run to run)
     for got, want, name in ((fused[0].float(), gv.float(), "grad_value"), (fused[1], go, "grad_offsets"),
                             (fused[2], rows, "grad_ref_rows")):
