@@ -837,7 +837,8 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
     p = DensePlan{};
     p.dbg = g_dense_dbg.load();
     p.L = d.L; p.B = d.B; p.Lq = d.Lq; p.S = d.S; p.H = d.H;
-    p.rcp_h = 1.0f / (float)d.H;
+    const auto magic = [](int dd) { return dd == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)dd); };
+    p.mag_h = magic(d.H);
     long long next = 0;
     for (int l = 0; l < d.L; ++l) {
         const long long hl = sh[2 * l], wl = sh[2 * l + 1];
@@ -847,9 +848,10 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
         v.H = (int)hl; v.W = (int)wl; v.start = (int)ls[l];
         v.ntx = (int)((wl + kDenseTile - 1) / kDenseTile);
         v.ntiles = v.ntx * (int)((hl + kDenseTile - 1) / kDenseTile);
-        if ((long long)v.ntiles * d.B * d.H >= (1 << 20)) return false;      // float divisions, x * n < 2^23
-        v.rcp_ntx = 1.0f / (float)v.ntx;
-        v.rcp_ntiles = 1.0f / (float)v.ntiles;
+        if ((long long)v.ntiles * d.B * d.H >= (1 << 24)) return false;      // x * n and the block index < 2^31
+        v.n_all = (unsigned)(v.ntiles * d.B);
+        v.mag_ntx = magic(v.ntx);
+        v.mag_ntiles = magic(v.ntiles);
     }
     if (next != d.S) return false;
     // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
@@ -867,8 +869,10 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             const float mx = rx * ref4 * (1.0f + jit), my = ry * ref4 * (1.0f + jit);
             const int cols = (int)std::ceil(rx * (kDenseTile - 1) + 2 * mx) + 2;
             const int rows = (int)std::ceil(ry * (kDenseTile - 1) + 2 * my) + 2;
-            w.ax = kDenseTile * rx; w.bx = 0.5f * rx - 0.5f - mx;
-            w.ay = kDenseTile * ry; w.by = 0.5f * ry - 0.5f - my;
+            // 16.16 fixed point (a placement heuristic: any rounding will do, tile columns < 2^12)
+            w.ax = (int)std::lround(kDenseTile * rx * 65536.0f); w.bx = (int)std::floor((0.5f * rx - 0.5f - mx) * 65536.0f);
+            w.ay = (int)std::lround(kDenseTile * ry * 65536.0f); w.by = (int)std::floor((0.5f * ry - 0.5f - my) * 65536.0f);
+            if (rx > 8.0f || ry > 8.0f) { w.ax = w.ay = 0; }      // (not staged anyway; keeps tx * ax inside 31 bits)
             const int pitch = cols + 2;             // slots of neighbouring rows start 2 bank groups apart
             const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots;
             w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, pitch, used);

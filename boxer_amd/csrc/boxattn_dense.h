@@ -42,17 +42,6 @@ namespace boxattn {
 #endif
 typedef unsigned int dense_u32x4 __attribute__((ext_vector_type(4)));
 
-// n / d, n % d for 0 <= n < 2^24 (float estimate + correction), d > 0
-__device__ __forceinline__ void dense_divmod(unsigned n, int d, float rcp, unsigned &q, unsigned &r)
-{
-    int qi, ri;
-    divmod_small((int)n, d, rcp, qi, ri);
-    // the operands are wave-uniform, the float estimate runs on the VALU: tell the compiler the
-    // results are uniform again (everything derived from them then stays in scalar registers)
-    q = (unsigned)__builtin_amdgcn_readfirstlane(qi);
-    r = (unsigned)__builtin_amdgcn_readfirstlane(ri);
-}
-
 // one 64-byte row (32 bf16 channels) as 16 words.  (The words go through a plain array: a bit_cast
 // of element i of an ext_vector selects element 0 for every i with this compiler)
 template <typename PTR> __device__ __forceinline__ void dense_load_row(PTR p, unsigned (&w)[16])
@@ -83,13 +72,15 @@ __device__ __forceinline__ float dense_dot_row(const unsigned (&g)[16], const un
 // spatial band of the maps -- and walks the levels coarsest first, because the tiles of the coarse
 // levels are the slow ones (their fine-level points take the global path).
 //
-// All of it is scalar work at the top of every wave, and it used to be a third of a wave's life: the
-// plan lives in the kernel-argument segment, every field read is a scalar load, and reads behind a
-// branch or at a computed offset were issued one by one, each with its own wait (s_memtime stamps:
-// 6 600 of 17 700 cycles before the first row request left).  So: every statically addressed field
-// is read up front in straight-line code (one batch, one wait), the search over the levels is
-// branch-free, the query level's entry is selected from the registers, and the only reads at a
-// computed offset -- the L windows of the query level -- form one batch.
+// All of it is scalar work at the top of every wave -- and scalar instructions are not free: the CU's
+// one scalar unit serves its four SIMDs, an s_ instruction costs a wave as much issue time as a vector
+// one (PMC: all kernels of the step retire ~1 instruction per 4 cycles and SIMD whatever the mix).  The
+// decode is therefore integer-only (multiply-high divisions with host magic numbers, 16.16 fixed-point
+// window origins: ~100 scalar instructions; with float estimates and v_readfirstlane it was ~450), and
+// it reads the plan in two batches: what is addressed statically up front, the query level's entry and
+// its L windows -- the only reads at a computed offset -- right after the level is known (read one by
+// one behind branches they were a third of a wave's life: 6 600 of 17 700 cycles before the first row
+// request left, s_memtime stamps).
 struct DenseTileId {
     int lq;                  // query level, -1: no tile
     unsigned b;
@@ -99,47 +90,44 @@ struct DenseTileId {
 struct DenseMap { int H, W, start; };                   // what the kernel keeps of a level
 template <int L> struct DenseHot {
     DenseMap lv[L];
-    int B, H, Lq, S;
+    int H, Lq, S;
 };
 template <int L>
 __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, unsigned block,
-                                                           DenseHot<L> &hot, DenseMap &Q)
+                                                           DenseHot<L> &hot, DenseMap &Q, DenseWin (&wrow)[L])
 {
-    DenseLevel lv[L];                                    // (the tile counts and reciprocals die with the decode)
+    unsigned n_all[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        lv[l] = pl.lv[l];
-        hot.lv[l] = DenseMap{lv[l].H, lv[l].W, lv[l].start};
+        hot.lv[l] = DenseMap{pl.lv[l].H, pl.lv[l].W, pl.lv[l].start};
+        n_all[l] = pl.lv[l].n_all;
     }
-    hot.B = pl.B; hot.H = pl.H; hot.Lq = pl.Lq; hot.S = pl.S;
+    hot.H = pl.H; hot.Lq = pl.Lq; hot.S = pl.S;
     DenseTileId t;
     const unsigned x = block & 7u;
     unsigned j, h;
-    dense_divmod(block >> 3, hot.H, pl.rcp_h, j, h);
+    divmod_magic(block >> 3, (unsigned)hot.H, pl.mag_h, j, h);
     t.h = (int)h;
     int lq = -1;
     unsigned ti = 0, first = 0;
-    DenseLevel q = lv[0];
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
-        const unsigned n = (unsigned)hot.B * (unsigned)lv[l].ntiles;
-        const unsigned lo = (x * n) >> 3, hi = ((x + 1) * n) >> 3;
-        const bool here = j >= first && j < first + (hi - lo);
+        const unsigned lo = (x * n_all[l]) >> 3, cnt = (((x + 1) * n_all[l]) >> 3) - lo;
+        const bool here = j - first < cnt;                 // first <= j < first + cnt
         lq = here ? l : lq;
         ti = here ? lo + (j - first) : ti;
-        q.H = here ? lv[l].H : q.H;           q.W = here ? lv[l].W : q.W;
-        q.start = here ? lv[l].start : q.start;
-        q.ntx = here ? lv[l].ntx : q.ntx;     q.ntiles = here ? lv[l].ntiles : q.ntiles;
-        q.rcp_ntx = here ? lv[l].rcp_ntx : q.rcp_ntx;
-        q.rcp_ntiles = here ? lv[l].rcp_ntiles : q.rcp_ntiles;
-        first += hi - lo;
+        first += cnt;
     }
     t.lq = lq;
     t.group = (int)(ti & (unsigned)(kDenseGroups - 1));
+    const int lqc = max(lq, 0);
+    const DenseLevel q = pl.lv[lqc];                       // the reads at a computed offset: one batch
+#pragma unroll
+    for (int l = 0; l < L; ++l) wrow[l] = pl.win[lqc][l];
     Q = DenseMap{q.H, q.W, q.start};
     unsigned tr, ty, tx;
-    dense_divmod(ti, q.ntiles, q.rcp_ntiles, t.b, tr);
-    dense_divmod(tr, q.ntx, q.rcp_ntx, ty, tx);
+    divmod_magic(ti, (unsigned)q.ntiles, q.mag_ntiles, t.b, tr);
+    divmod_magic(tr, (unsigned)q.ntx, q.mag_ntx, ty, tx);
     t.ty = (int)ty;
     t.tx = (int)tx;
     return t;
@@ -173,27 +161,29 @@ __device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const 
         const DenseWin w = wrow[l];
         DenseWinPos &o = win[l];
         o.geo = w.geo;
-        const int x0 = (int)floorf((float)t.tx * w.ax + w.bx), y0 = (int)floorf((float)t.ty * w.ay + w.by);
-        o.x0 = __builtin_amdgcn_readfirstlane(max(0, min(x0, T.W - o.cols())));
-        o.y0 = __builtin_amdgcn_readfirstlane(max(0, min(y0, T.H - o.rows())));
+        const int x0 = (t.tx * w.ax + w.bx) >> 16, y0 = (t.ty * w.ay + w.by) >> 16;
+        o.x0 = max(0, min(x0, T.W - o.cols()));
+        o.y0 = max(0, min(y0, T.H - o.rows()));
         const int jx = min(o.x0 + j, T.W - 1);
         const unsigned voff =
             ((((t.b * (unsigned)hot.S + (unsigned)(T.start + jx)) * (unsigned)hot.H + (unsigned)t.h) * C) +
              (unsigned)chunk * 8u) * 2u;
         const unsigned row_bytes = (unsigned)T.W * (unsigned)hot.H * (C * 2u);
+        // (rows past the bottom of the map -- a window taller than the map -- are never looked up: a
+        // corner row that counts lies inside the map; they are simply not fetched)
+        const int rows = min(o.rows(), T.H - o.y0);
+        unsigned soff = (unsigned)(o.y0 + wv) * row_bytes;
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
-            const int r = wv + 4 * k;
-            if (r < o.rows()) {                                        // wave-uniform
-                const unsigned soff = (unsigned)min(o.y0 + r, T.H - 1) * row_bytes;
+            if (wv + 4 * k < rows)                                     // wave-uniform
                 st.reg[l][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-            }
+            soff += 4u * row_bytes;
         }
     }
 }
 
 template <int L>
-__device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned char *lds,
+__device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned char *lds, const DenseMap (&maps)[L],
                                                    const DenseWinPos (&win)[L], const DenseStageRegs<L> &st)
 {
     constexpr int RPW = kDenseWinMax / 4;
@@ -201,12 +191,15 @@ __device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned ch
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const DenseWinPos &o = win[l];
-        unsigned char *dst = lds + __mul24(o.off() + j, kDenseSlotBytes) + chunk * 16;
+        const int rows = min(o.rows(), maps[l].H - o.y0);
+        const int step = __mul24(o.pitch(), 4 * kDenseSlotBytes);
+        unsigned char *dst = lds + __mul24(o.off() + j + wv * o.pitch(), kDenseSlotBytes) + chunk * 16;
+        if (j < o.cols()) {
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const int r = wv + 4 * k;
-            if (r < o.rows() && j < o.cols())
-                *reinterpret_cast<dense_u32x4 *>(dst + __mul24(r * o.pitch(), kDenseSlotBytes)) = st.reg[l][k];
+            for (int k = 0; k < RPW; ++k) {
+                if (wv + 4 * k < rows) *reinterpret_cast<dense_u32x4 *>(dst) = st.reg[l][k];
+                dst += step;
+            }
         }
     }
 }
@@ -274,30 +267,37 @@ __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             off[k] = (unsigned)(((row0 + (unsigned)s.pix[k]) * H + h) * (C * 2)) + (unsigned)p * 16u;
-        const unsigned okm = (s.ok[0] ? 1u : 0u) | (s.ok[1] ? 2u : 0u) | (s.ok[2] ? 4u : 0u) | (s.ok[3] ? 8u : 0u) |
-                             (slow ? 16u : 0u);
+        // two points of the quad at a time: their 8 row pieces are requested together and unconditionally
+        // (the offsets are always inside the map) -- one point at a time, each under its own "anyone
+        // slow?" branch, a level was four memory round trips in a row (s_memtime: 9 000 cycles a level)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned m_t = quad_bcast_u32(okm, t);
-            if (__builtin_amdgcn_ballot_w64((m_t & 16u) != 0u) == 0ull) continue;      // wave-uniform
-            float part[4];
+        for (int t0 = 0; t0 < 4; t0 += 2) {
+            dense_u32x4 v[2][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // (my own offset already carries my chunk: take lane t's row, keep my 16-byte piece)
-                const unsigned o = quad_bcast_u32(off[k] - (unsigned)p * 16u, t) + (unsigned)p * 16u;
-                dense_u32x4 v = {0u, 0u, 0u, 0u};
-                if (m_t & 16u) v = *reinterpret_cast<const dense_u32x4 *>(reinterpret_cast<const char *>(value) + o);
-                const unsigned vw[4] = {v.x, v.y, v.z, v.w};
-                float d = 0.f;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gch[i]),
-                                                        __builtin_bit_cast(bf16x2_t, vw[i]), d, false);
-                part[k] = group_sum<4>(d);
-            }
-            if (p == t && slow) {
+                for (int k = 0; k < 4; ++k) {
+                    // (my own offset already carries my chunk: take lane t's row, keep my 16-byte piece)
+                    const unsigned o = quad_bcast_u32(off[k] - (unsigned)p * 16u, t0 + u) + (unsigned)p * 16u;
+                    v[u][k] = *reinterpret_cast<const dense_u32x4 *>(reinterpret_cast<const char *>(value) + o);
+                }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sk[k] = s.ok[k] ? part[k] : 0.f;
+            for (int u = 0; u < 2; ++u) {
+                float part[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned vw[4] = {v[u][k].x, v[u][k].y, v[u][k].z, v[u][k].w};
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gch[i]),
+                                                            __builtin_bit_cast(bf16x2_t, vw[i]), d, false);
+                    part[k] = group_sum<4>(d);
+                }
+                if (p == t0 + u && slow) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sk[k] = s.ok[k] ? part[k] : 0.f;
+                }
             }
         }
     }
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void dense_count_kernel(const float *__restric
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     DenseHot<L> hot;
     DenseMap Q;
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q);
+    DenseWin wrow[L];
+    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q, wrow);
     if (t.lq < 0) return;                                          // workgroup-uniform
     const int qi = lane >> 2, p = lane & 3;
     const int qy = t.ty * kDenseTile + (wv >> 1) * kDenseSub + (qi >> 2);
@@ -407,11 +408,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
 #endif
     DenseHot<L> hot;
     DenseMap Q;
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q);
-    if (t.lq < 0) return;                                          // workgroup-uniform
     DenseWin wrow[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) wrow[l] = pl.win[t.lq][l];
+    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q, wrow);
+    if (t.lq < 0) return;                                          // workgroup-uniform
     const int H = hot.H, h = t.h;
     if constexpr (FILL) {
         dense_tab_zero(dense_tab, bin.nblk);
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     DENSE_STAMP();                                                 // everything has arrived
 #endif
     // FILL: the ranks of the lane's points in their bins (LDS atomics) behind the staging stores
-    dense_stage_commit<L>(lane, wv, win_lds, win, stage);
+    dense_stage_commit<L>(lane, wv, win_lds, hot.lv, win, stage);
     unsigned ranks[FILL ? L : 1];          // (after the staging stores: their 64 registers are free again)
     if constexpr (FILL) {
 #pragma unroll

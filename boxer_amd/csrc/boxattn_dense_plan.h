@@ -20,13 +20,14 @@ constexpr int kDenseSlots = 480;           // staged pixels per workgroup (38 40
 struct DenseLevel {
     int H, W, start;         // map size, first row of the level in `value`
     int ntx, ntiles;         // tiles per tile row, tiles per image
-    float rcp_ntx, rcp_ntiles;
+    unsigned n_all;          // B * ntiles
+    unsigned mag_ntx, mag_ntiles;    // floor(2^32 / d) (0xFFFFFFFF for d = 1): divmod_magic()
 };
 // window of level l for a tile of level lq: first column floor(tx * ax + bx) (tx = tile column),
 // first row floor(ty * ay + by), clamped into the map; rows == 0: not staged (global path only).
 // Staged pixel (r, c) of the window lives in slot off + r * pitch + c.
 struct DenseWin {
-    float ax, bx, ay, by;
+    int ax, bx, ay, by;      // 16.16 fixed point: first column (tx * ax + bx) >> 16, first row alike
     unsigned geo;            // rows | cols << 5 | pitch << 10 | off << 16 (one scalar register, see dense_win_*)
 };
 inline unsigned dense_win_pack(int rows, int cols, int pitch, int off)
@@ -35,7 +36,7 @@ inline unsigned dense_win_pack(int rows, int cols, int pitch, int off)
 }
 struct DensePlan {
     int L, B, Lq, S, H;
-    float rcp_h;
+    unsigned mag_h;          // floor(2^32 / H)
     DenseLevel lv[kDenseMaxLevels];
     DenseWin win[kDenseMaxLevels][kDenseMaxLevels];      // [query level][sampled level]
     float *dbg;              // debugging aid (builds with BOXATTN_DENSE_DEBUG; boxattn_set_debug_buffer)
