@@ -39,6 +39,7 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptDense = 11,        // dense (matrix-core) encoder kernels: 0 default (BOXATTN_DENSE_DEFAULT), 1 off, 2 on
        kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
+       kOptScanTail = 15,     // training forward: the block scans ride in the forward kernel's launch: 0 default (on), 1 off
        kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
        kNumOpts = 16 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
@@ -318,8 +319,12 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                const typename Storage<ST>::compute *w_sp,
                const typename Storage<ST>::compute *w_lv, const Dims &d, ST *out, ST *mask,
                hipStream_t st, const int64_t *shapes_host = nullptr,
-               const int64_t *lsi_host = nullptr)
+               const int64_t *lsi_host = nullptr, const ScanTail *scan_tail = nullptr,
+               bool *scan_tail_taken = nullptr)
 {
+    // scan_tail: the backward's block scans to run as extra workgroups of the forward kernel (training
+    // forward); *scan_tail_taken says whether the kernel that was launched carried them
+    if (scan_tail_taken) *scan_tail_taken = false;
     if (!d.valid()) return (int)hipErrorInvalidValue;
     if (d.empty()) return 0;                                   // no queries: nothing to write
     if (!shapes || !lsi || !loc || !w_sp || !out || (INST && (!w_lv || !mask)))
@@ -384,13 +389,19 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                 }
             }
             if (gen2) {
+                const bool tail = !INST && scan_tail && scan_tail->n_wg > 0 && fsplit == 1;
+                const ScanTail sct = tail ? *scan_tail : ScanTail{};
+                const int tail_blocks = tail ? sct.plan.n_slices * kScanSub : 0;        // in FRONT of the grid (kScanSub = 8 each)
+                ix.lead = (unsigned)tail_blocks;
 #define BOXATTN_FWD2(GG, VV)                                                                  \
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
-                       dim3(blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
+                       dim3(blocks + tail_blocks, fsplit), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, \
                        w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask,                             \
-                       with_grid(ix, blocks, fsplit, (d.P + GG - 1) / GG), (unsigned)vbytes);
+                       with_grid(ix, blocks, fsplit, (d.P + GG - 1) / GG), (unsigned)vbytes,  \
+                       GridSrc{}, sct);
                 BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2);
 #undef BOXATTN_FWD2
+                if (tail && scan_tail_taken) *scan_tail_taken = true;
             } else {
 #define BOXATTN_FWD_CASE(GG)                                                                  \
     case GG:                                                                                  \
@@ -649,7 +660,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct WsLayout {
     size_t n_items;
-    size_t part, subtot, offsets, items, combos, records, partials, scan_tmp, cursor, total;
+    size_t part, tickets, subtot, offsets, items, combos, records, partials, scan_tmp, cursor, total;
     int q_per_wg, n_wg;                                     // launch geometry of the bin passes
 };
 
@@ -729,6 +740,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
     size_t o = 0;
     w.n_items = o; o += align_up(ns * 2 * 4);
     w.part = o;    o += align_up(ns * std::max(w.n_wg, kDenseGroups) * (size_t)p.nblk * 4);
+    w.tickets = o; o += align_up(ns * 4);        // the scans riding in the forward kernel's launch (ScanTail)
     w.subtot = o;  o += align_up(ns * kScanSub * (size_t)p.nblk * 4);
     w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
     w.items = o;   o += align_up(ns * p.item_cap * 16);
@@ -751,20 +763,39 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
 // read the sampling locations, so the training forward can run them ahead of the backward.
 template <bool WIDE, bool INTERLEAVE>
 inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                             const WsLayout &w, char *ws, hipStream_t st);
+                             const WsLayout &w, char *ws, hipStream_t st, int stages);
 // wide: 16-byte records; interleave: queries interleaved over the bin workgroups (VALU accumulate)
+// stages: kBinCount | kBinScan | kBinFill (all three in one call, or -- the training forward, which
+// lets the scans ride in the forward kernel's launch -- one at a time)
+enum { kBinCount = 1, kBinScan = 2, kBinFill = 4, kBinAll = 7,
+       kBinTickets = 8 };    // with kBinCount: clear the tickets of the scans that will ride in the forward kernel
 inline void launch_binning(bool wide, bool interleave, const float *loc, const float *w_sp,
                            const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws,
-                           hipStream_t st)
+                           hipStream_t st, int stages = kBinAll)
 {
-    if (wide && interleave) launch_binning_t<true, true>(loc, w_sp, d, plan, w, ws, st);
-    else if (wide) launch_binning_t<true, false>(loc, w_sp, d, plan, w, ws, st);
-    else if (interleave) launch_binning_t<false, true>(loc, w_sp, d, plan, w, ws, st);
-    else launch_binning_t<false, false>(loc, w_sp, d, plan, w, ws, st);
+    if (wide && interleave) launch_binning_t<true, true>(loc, w_sp, d, plan, w, ws, st, stages);
+    else if (wide) launch_binning_t<true, false>(loc, w_sp, d, plan, w, ws, st, stages);
+    else if (interleave) launch_binning_t<false, true>(loc, w_sp, d, plan, w, ws, st, stages);
+    else launch_binning_t<false, false>(loc, w_sp, d, plan, w, ws, st, stages);
+}
+// Can the two scan kernels of this plan run as bin_scan_tail_body workgroups?
+inline bool scan_tail_ok(const BinPlan &plan, const WsLayout &w)
+{
+    return opt(kOptScanTail) != 1 && plan.nblk <= kScanThreads && w.n_wg <= kScanSub * kScanWgPerSub;
+}
+inline ScanTail scan_tail(const BinPlan &plan, const WsLayout &w, char *ws)
+{
+    ScanTail t{};
+    t.subtot = (int *)(ws + w.subtot); t.offsets = (int *)(ws + w.offsets);
+    t.items = (int4 *)(ws + w.items); t.combos = (int4 *)(ws + w.combos);
+    t.n_items = (int *)(ws + w.n_items); t.part = (int *)(ws + w.part); t.tickets = (int *)(ws + w.tickets);
+    t.plan = plan;
+    t.n_wg = w.n_wg;
+    return t;
 }
 template <bool WIDE, bool INTERLEAVE>
 inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                             const WsLayout &w, char *ws, hipStream_t st)
+                             const WsLayout &w, char *ws, hipStream_t st, int stages)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
@@ -794,17 +825,20 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
                                dim3(kBinThreads), bsh, st, loc, w_sp, plan, d.H, d.Lq, d.P,        \
                                w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
     } while (0)
-    BOXATTN_BIN(false);
+    if (stages & kBinTickets) hipMemsetAsync(ws + w.tickets, 0, (size_t)ns * sizeof(int), st);
+    if (stages & kBinCount) BOXATTN_BIN(false);
 #ifndef BOXATTN_TUNE_SCAN_FUSE_WG
 #define BOXATTN_TUNE_SCAN_FUSE_WG 48   // up to this many bin workgroups per slice the block scan does kernel A's work too
                                        // (38 workgroups, the 300-query decoders: C3'' fp32 68 -> 61 us; 64, C2: binning 49 -> 61 us)
 #endif
     const bool fuse_a = plan.nblk <= kScanThreads && w.n_wg <= BOXATTN_TUNE_SCAN_FUSE_WG;
-    if (!fuse_a)
+    if (!(stages & kBinScan)) {
+    } else if (!fuse_a)
         hipLaunchKernelGGL(bin_scan_a_kernel,
                            dim3(kScanSub, ns, std::min(64, (plan.nblk + 255) / 256)), dim3(256), 0, st,
                            part, w.n_wg, subtot, plan);
-    if (plan.nblk > kScanThreads) {                  // big maps: the block scan over several CUs
+    if (!(stages & kBinScan)) {
+    } else if (plan.nblk > kScanThreads) {           // big maps: the block scan over several CUs
         const int nseg = (plan.nblk + kScanThreads - 1) / kScanThreads;
         int4 *tmp = (int4 *)(ws + w.scan_tmp), *segtot = tmp + (size_t)ns * plan.nblk;
         hipLaunchKernelGGL(bin_scan_seg_kernel, dim3(nseg, ns), dim3(kScanThreads), 0, st, subtot,
@@ -815,7 +849,7 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
         hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets,
                            items, combos, n_items, plan, part, fuse_a ? w.n_wg : 0);
     }
-    BOXATTN_BIN(true);
+    if (stages & kBinFill) BOXATTN_BIN(true);
 #undef BOXATTN_BIN
 }
 
@@ -1401,8 +1435,20 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         }
     }
     SideStream side(st, side_stream_worth<ST>(d));
-    launch_binning(wide_records<ST, INST>(d), !mfma_accumulate<ST, INST>(d), loc, w_sp, d, plan, w,
-                   (char *)workspace, side.stream());
+    const bool wide = wide_records<ST, INST>(d), inter = !mfma_accumulate<ST, INST>(d);
+    if (!INST && side.stream() == st && scan_tail_ok(plan, w)) {
+        // count -> forward kernel + the scans as extra workgroups of its launch -> fill
+        launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, st, kBinCount | kBinTickets);
+        const ScanTail tail = scan_tail(plan, w, (char *)workspace);
+        bool taken = false;
+        const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                            shapes_host, lsi_host, &tail, &taken);
+        launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, st,
+                       taken ? kBinFill : (kBinScan | kBinFill));
+        if (rc == 0 && plan_built) *plan_built = 1;
+        return rc;
+    }
+    launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, side.stream());
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
                                         shapes_host, lsi_host);
     side.join();

@@ -258,6 +258,7 @@ struct GatherIdx {
     // at the top of every wave) and `tiles per workgroup` was an emulated integer division there
     unsigned grid_x, grid_y;
     unsigned tps;         // point tiles per workgroup row: ceil(tiles / grid_y)
+    unsigned lead;        // workgroups in front of the kernel's own (fwd2_kernel: the scan workgroups)
 };
 
 // Which (query, head) pair a lane group works on.
@@ -271,13 +272,14 @@ __device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, int H, int
                                                  bool &active)
 {
     unsigned qh;
+    const unsigned blk = blockIdx.x - ix.lead;            // (lead: scan workgroups in front, a multiple of 8)
     if (ix.head_xcd) {
-        const unsigned tile = (blockIdx.x / 8) * kGatherWaves + wv;
+        const unsigned tile = (blk / 8) * kGatherWaves + wv;
         const unsigned bq = tile * PAIRS + j;
         active = bq < ix.n_qh / (unsigned)H;
-        qh = bq * (unsigned)H + blockIdx.x % 8;
+        qh = bq * (unsigned)H + blk % 8;
     } else {
-        const unsigned bid = xcd_chunked_block(blockIdx.x, ix.grid_x);
+        const unsigned bid = xcd_chunked_block(blk, ix.grid_x);
         qh = (bid * kGatherWaves + wv) * PAIRS + j;
         active = qh < ix.n_qh;
     }
@@ -297,10 +299,21 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
-    GridSrc gs = GridSrc{})
+    GridSrc gs = GridSrc{}, ScanTail sct = ScanTail{})
 {
     static_assert(!(GRID && INST), "boxes -> grid is built for box attention");
     constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
+    if constexpr (!INST && !GRID) {
+        // the training forward: the backward's two scan kernels as one extra workgroup per slice
+        // (bin_scan_tail_body): they only need the count pass, which ran before this launch
+        // (they take the FIRST workgroup ids -- dispatched first, done long before the forward's last
+        // workgroup)
+        if (sct.n_wg > 0 && blockIdx.x < ix.lead) {
+            if ((int)blockIdx.x < sct.plan.n_slices * kScanSub)
+                bin_scan_tail_body<256>(sct, (int)blockIdx.x / kScanSub, (int)blockIdx.x % kScanSub);
+            return;
+        }
+    }
     typedef GeoTile<G, NH> Tile;
     typedef Row<ST, VEC> RowT;
     constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;    // bytes between a lane's pieces

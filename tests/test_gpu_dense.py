@@ -137,3 +137,38 @@ def test_dense_kernels_skipped_points_write_zeros(dense_switch):
     assert torch.equal(ga[:, ::3], torch.zeros_like(ga[:, ::3]))
     for name, worst, tol in bench.parity_report(inp, out, grads):
         assert worst <= tol, (name, worst)
+
+
+OPT_SCAN_TAIL = 15      # 0 default (the block scans ride in the forward kernel's launch), 1 off
+
+
+def test_scans_inside_the_forward_launch_match_the_scan_kernels():
+    """The training forward runs the backward's two scan kernels as extra workgroups of the forward
+    kernel (bin_scan_tail_body: a ticket per slice, the last workgroup scans the blocks).  Same plan as
+    the stand-alone kernels -- compared through what the backward makes of it -- for both storage
+    types, and stable over many back-to-back steps (an inter-workgroup hand-off that goes stale shows
+    up as a wrong bin offset sooner or later)."""
+    from boxer_amd import ops
+    lib = _lib()
+    for dtype in (torch.bfloat16, torch.float32):
+        inp = bench.make_inputs("C2", dtype, "cuda", family="model", batch=2, seed=1)
+        v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
+        res = {}
+        for mode in (1, 0):
+            old = lib.boxattn_set_option(OPT_SCAN_TAIL, mode)
+            try:
+                outs = []
+                for it in range(60 if mode == 0 else 2):
+                    out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+                    gv, gl, ga = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
+                    outs.append((out, gv, gl, ga))
+                torch.cuda.synchronize()
+                res[mode] = outs
+            finally:
+                lib.boxattn_set_option(OPT_SCAN_TAIL, old)
+        ref = res[1][0]
+        for out, gv, gl, ga in res[0]:
+            assert torch.equal(out, ref[0]) and torch.equal(gl, ref[2]) and torch.equal(ga, ref[3])
+            err = (gv.float() - ref[1].float()).abs().max().item()
+            # (the order of the records inside a bin, hence the float32 summation order, may differ)
+            assert err <= (1e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, ref[1].float().abs().max().item())
