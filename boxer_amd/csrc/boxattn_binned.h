@@ -91,8 +91,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
                                                   int *__restrict__ part,
                                                   const int *__restrict__ subtot,
                                                   const int *__restrict__ offsets,
-                                                  int *__restrict__ records)
+                                                  int *__restrict__ records,
+                                                  int *__restrict__ tickets = nullptr)
 {
+    // count pass of a training forward whose scans ride in the forward kernel (ScanTail): clear the
+    // slices' tickets.  (Not a hipMemsetAsync in front: a memset node as the first node of a captured
+    // graph left the kernels behind it reading stale upstream gradients on replay.)
+    if (!FILL && tickets && blockIdx.x == 0 && threadIdx.x == 0) tickets[blockIdx.y] = 0;
     // part[slice][workgroup][block]: after the count pass the number of records this workgroup
     // has for the block; the scan kernel turns it into the workgroup's first slot inside the
     // block's bin.  No global atomics anywhere in the binning (they cost ~20 us per pass:
@@ -364,6 +369,9 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
 // Results as the two kernels'.  Inter-workgroup hand-off (MI355X_MICROARCH.md, inter-workgroup
 // visibility): agent-scope (write-through) stores of the totals -> s_waitcnt vmcnt(0) -> __syncthreads
 // -> relaxed agent atomic (the ticket); the last arriver reads them with agent-scope loads.
+#ifndef BOXATTN_TUNE_TAIL_ACQUIRE
+#define BOXATTN_TUNE_TAIL_ACQUIRE 0
+#endif
 struct ScanTail {
     int *subtot, *offsets;
     int4 *items, *combos;
@@ -416,6 +424,10 @@ __device__ __forceinline__ void bin_scan_tail_body(const ScanTail t, int s, int 
     }
     __syncthreads();
     if (ticket != kScanSub - 1) return;                               // workgroup-uniform
+#if BOXATTN_TUNE_TAIL_ACQUIRE
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, BOXATTN_TUNE_TAIL_ACQUIRE == 2 ? "" : "agent");
+    __syncthreads();
+#endif
     // ---- the slice's block scan (bin_scan_kernel)
     int c[PER], nch[PER], sum[4] = {0, 0, 0, 0};
 #pragma unroll

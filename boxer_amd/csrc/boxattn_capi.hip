@@ -47,6 +47,15 @@ inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
 inline int ceil_div_sz(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 
+// zero-fill on the stream (zero_fill_kernel, see there why not hipMemsetAsync)
+inline hipError_t zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    const int blocks = (int)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)p, bytes);
+    return hipGetLastError();
+}
+
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 struct Dims {
@@ -331,9 +340,9 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
         return (int)hipErrorInvalidValue;
     const size_t n_qh = d.n_qh();
     if (d.n_value() == 0) {                                    // no pixels: every sample is 0
-        hipError_t e = hipMemsetAsync(out, 0, n_qh * d.C * sizeof(ST), st);
+        hipError_t e = zero_async(out, n_qh * d.C * sizeof(ST), st);
         if (e == hipSuccess && INST)
-            e = hipMemsetAsync(mask, 0, n_qh * d.C * d.P * sizeof(ST), st);
+            e = zero_async(mask, n_qh * d.C * d.P * sizeof(ST), st);
         return (int)e;
     }
     if (!value) return (int)hipErrorInvalidValue;
@@ -368,7 +377,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             if (INST && gen2 && !wide && std::is_same<ST, float>::value)
                 fsplit = point_split(blocks, (d.P + G - 1) / G);
             if (fsplit > 1) {
-                hipError_t e = hipMemsetAsync(out, 0, n_qh * d.C * sizeof(ST), st);
+                hipError_t e = zero_async(out, n_qh * d.C * sizeof(ST), st);
                 if (e != hipSuccess) return (int)e;
             }
             ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
@@ -474,7 +483,7 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     const size_t n_qh = d.n_qh();
     if (nv) {
         if (!grad_value || !grad_value_acc) return (int)hipErrorInvalidValue;
-        hipError_t e = hipMemsetAsync(grad_value_acc, 0, nv * sizeof(T), st);
+        hipError_t e = zero_async(grad_value_acc, nv * sizeof(T), st);
         if (e != hipSuccess) return (int)e;
     }
     if (n_qh) {
@@ -483,9 +492,9 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             return (int)hipErrorInvalidValue;
         if (!nv) {                                             // no pixels: all gradients 0
             const size_t np = n_qh * d.L * d.P;
-            hipError_t e = hipMemsetAsync(grad_loc, 0, 2 * np * sizeof(T), st);
-            if (e == hipSuccess) e = hipMemsetAsync(grad_sp, 0, np * sizeof(T), st);
-            if (e == hipSuccess && INST) e = hipMemsetAsync(grad_lv, 0, np * sizeof(T), st);
+            hipError_t e = zero_async(grad_loc, 2 * np * sizeof(T), st);
+            if (e == hipSuccess) e = zero_async(grad_sp, np * sizeof(T), st);
+            if (e == hipSuccess && INST) e = zero_async(grad_lv, np * sizeof(T), st);
             return (int)e;
         }
         if (!value) return (int)hipErrorInvalidValue;
@@ -819,14 +828,15 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
         if (pt4 && (WIDE || !FILL_))                                                               \
             hipLaunchKernelGGL((bin_kernel<BW, BH, FILL_, WIDE, INTERLEAVE, 4>), bgrid,            \
                                dim3(kBinThreads), bsh, st, loc, w_sp, plan, d.H, d.Lq, d.P,        \
-                               w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
+                               w.q_per_wg, w.n_wg, part, subtot, offsets, records, tickets);       \
         else                                                                                       \
             hipLaunchKernelGGL((bin_kernel<BW, BH, FILL_, WIDE, INTERLEAVE, 1>), bgrid,            \
                                dim3(kBinThreads), bsh, st, loc, w_sp, plan, d.H, d.Lq, d.P,        \
-                               w.q_per_wg, w.n_wg, part, subtot, offsets, records);                \
+                               w.q_per_wg, w.n_wg, part, subtot, offsets, records, tickets);       \
     } while (0)
-    if (stages & kBinTickets) hipMemsetAsync(ws + w.tickets, 0, (size_t)ns * sizeof(int), st);
+    int *tickets = (stages & kBinTickets) ? (int *)(ws + w.tickets) : nullptr;     // cleared by the count pass
     if (stages & kBinCount) BOXATTN_BIN(false);
+    tickets = nullptr;
 #ifndef BOXATTN_TUNE_SCAN_FUSE_WG
 #define BOXATTN_TUNE_SCAN_FUSE_WG 48   // up to this many bin workgroups per slice the block scan does kernel A's work too
                                        // (38 workgroups, the 300-query decoders: C3'' fp32 68 -> 61 us; 64, C2: binning 49 -> 61 us)
@@ -959,8 +969,8 @@ inline void launch_dense_binning(const float *loc, const Dims &d, const BinPlan 
     int *n_items = (int *)(ws + w.n_items), *offsets = (int *)(ws + w.offsets);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     const size_t gbytes = (size_t)ns * kDenseGroups * plan.nblk * sizeof(int);
-    hipMemsetAsync(part, 0, gbytes, st);
-    hipMemsetAsync(ws + w.cursor, 0, gbytes, st);
+    zero_async(part, gbytes, st);
+    zero_async(ws + w.cursor, gbytes, st);
     launch_dense_count(loc, dp, dense_bin(plan, part, nullptr, nullptr, nullptr, nullptr), st);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items, combos,
                        n_items, plan, part, kDenseGroups);
