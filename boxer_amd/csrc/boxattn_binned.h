@@ -58,17 +58,6 @@ __device__ __forceinline__ unsigned pack_block_geo(const BinLevel &lv, int level
 #ifndef BOXATTN_TUNE_INTERLEAVE
 #define BOXATTN_TUNE_INTERLEAVE 1
 #endif
-// Which slices (image, head) an XCD's accumulate workers take: CONSECUTIVE ones (1), i.e. with
-// two slices per XCD the heads 2j and 2j + 1 of one image -- the two 64-byte (bf16) halves of
-// every 128-byte line of grad_out they read and of grad_value they write then meet in ONE L2 --
-// or every 8th (0: head x of every image, the round-1 mapping: half lines in two L2s).
-#ifndef BOXATTN_TUNE_SLICE_MAP
-#define BOXATTN_TUNE_SLICE_MAP 1
-#endif
-__device__ __forceinline__ int slice_on_xcd(int xcd, int i, int per_xcd)
-{
-    return BOXATTN_TUNE_SLICE_MAP ? xcd * per_xcd + i : xcd + 8 * i;
-}
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // bin_scan_a_kernel: sub-ranges of workgroups
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,271 @@
+// The matrix-core accumulate of the destination-binned backward (boxattn_binned_mfma.h: one round of
+// 64 records against the 32 pixels of a block is the product grad_value^T[c][pixel] += G^T[c][k] A^T[k][pixel])
+// for bf16 storage, rebuilt around the instruction count.  The SQ counters of round 3
+// show every kernel of the step retiring one instruction per SIMD every ~4 cycles whatever its type --
+// scalar instructions included -- so the 420 instructions binned_accumulate_mfma_kernel issues per round
+// ARE its 50 us.  Where they went, and what replaces them:
+//
+//   * G^T staging (~70): the gathered upstream rows were transposed in registers (DPP swaps + v_perm) and
+//     written as dwords, because both MFMA operands want their K (= record) index contiguous per lane.
+//     Here the rows go to LDS as they arrive -- G[record][channel], one ds_write_b128 per lane and pass,
+//     4 KB with no padding -- and the operand is read with ds_read_b64_tr_b16, gfx950's transposing LDS
+//     read: a 16-lane group reads a [4 records][16 channels] block (every lane supplies the address of 4
+//     consecutive channels of one record) and lane i receives channel i of the 4 records.  Two reads =
+//     the lane's 8 consecutive k.  Four records x 64 bytes are one 256-byte bank row: conflict-free.
+//   * A^T scatter (~170): each of a record's 4 weights was stored under an exec mask of its own (in this
+//     block? lane live?), 17 s_and_saveexec / s_or pairs a round, the validity flags combined in scalar
+//     registers.  Here: a record exists only for a point that passed the window test (bin_kernel), and a
+//     block lies inside its map, so "corner inside the block" is the only test left -- done on integer
+//     row / column offsets that are `big` when outside, slot = min(row + column, dump slot).  All twelve
+//     stores (hi term, lo term, clear) are unconditional; corners outside go to a row nobody reads.
+//   * row addresses (~30): 32-bit offsets into a buffer resource instead of 64-bit pointer arithmetic.
+//   * the store: lanes l and l + 32 exchange half of their packed rows with v_permlane32_swap (4
+//     instructions) instead of 4 ds_bpermute + 12 selects.
+//
+// Same records, same items, same results (the order of the float32 products inside a weight differs:
+// (hh a) hw instead of (hh hw) a) as binned_accumulate_mfma_kernel, which stays for float32 storage
+// (variant 11) and as the A/B partner (boxattn_set_option(16, 1)).
+#pragma once
+#include "boxattn_binplan.h"
+
+namespace boxattn {
+
+#ifndef BOXATTN_TUNE_TR_WPE
+#define BOXATTN_TUNE_TR_WPE 4
+#endif
+
+typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float tr_f32x16 __attribute__((ext_vector_type(16)));
+typedef short tr_i16x4 __attribute__((ext_vector_type(4)));
+// 4 x 16 bits through the transposing read (see above); `p` is a byte address inside the workgroup's LDS
+__device__ __forceinline__ uint2 lds_read_tr16(const unsigned short *base, unsigned byte_off)
+{
+    typedef __attribute__((address_space(3))) tr_i16x4 lds_vec;
+    const tr_i16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_vec *)(reinterpret_cast<const char *>(base) + byte_off));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BOXATTN_TUNE_TR_WPE : 1))) void binned_accumulate_tr_kernel(
+    const ST *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
+    const int4 *__restrict__ items, const int *__restrict__ n_items,
+    const int *__restrict__ records, ST *__restrict__ grad_value, float *__restrict__ partials)
+{
+    static_assert(sizeof(ST) == 2, "bf16 storage");
+    static_assert(C == 16 || C == 32 || C == 64, "channels per head");
+    constexpr int BW = 8, PB = 32, R = 64;
+    constexpr int CP = C < 32 ? 32 : C;            // operand rows: channels padded to the MFMA's 32
+    constexpr int NCB = CP / 32;                   // 32-channel blocks
+    constexpr int ROWB = C * 2;                    // bytes of one upstream-gradient row
+    constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each
+    constexpr int RPP = 64 / LPR;                  // rows fetched per pass
+    constexpr int NPASS = R / RPP;
+    constexpr int GPL = R * 64;                    // bytes of one G plane: [record][32 channels]
+    constexpr int AS = 72;                         // ushorts per A^T row (36 dwords: 16-byte aligned rows, conflict-free operand reads)
+    constexpr int ASB = AS * 2;
+    constexpr int kDump = PB * ASB;                // byte offset of the row that takes the weights of corners outside the block
+    constexpr int kBig = 1 << 20;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned short gs[NCB * GPL / 2];
+    __shared__ __attribute__((aligned(16))) unsigned short at[(PB + 1) * AS];
+
+    // workgroup -> (slice, worker): all workers of a slice on one XCD (see binned_accumulate_kernel)
+    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = bid % 8, kq = bid / 8;
+    const int per_xcd = (n_slices + 7) / 8;
+    const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
+    const int worker = kq / per_xcd;
+    if (s >= n_slices || worker >= workers) return;
+    const int b = s / H, h = s % H;
+    const int lane = threadIdx.x;
+    const int col = lane & 31, kb = lane >> 5;     // operand row / column, k-block
+    const int n_it = n_items[2 * s];
+
+    for (int i = lane; i < (PB + 1) * AS / 2; i += 64) reinterpret_cast<unsigned int *>(at)[i] = 0u;
+    if (C < CP)                                     // the padding channels stay zero
+        for (int i = lane; i < NCB * GPL / 4; i += 64) reinterpret_cast<unsigned int *>(gs)[i] = 0u;
+    wave_lds_sync();
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<ST *>(grad_out), 0, grad_out_bytes, 0x00020000);
+    const unsigned slice_off = (unsigned)((b * Lq) * H + h) * (unsigned)ROWB;   // byte offset of (b, query 0, h)
+    const unsigned q_stride = (unsigned)(H * ROWB);
+    const int piece = lane % LPR, jrow = lane / LPR;
+    // staging: record jrow (+ RPP per pass), 16-byte piece `piece` of its row -> plane piece / 4
+    const unsigned stage_off = (unsigned)((piece >> 2) * GPL + jrow * 64 + (piece & 3) * 16);
+    // operand read: 16-lane group g reads records 8 (g >> 1) + 0..3 (+ 4), channels 16 (g & 1) + 0..15
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const unsigned tr_off = (unsigned)((8 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2);
+    const unsigned a_off = (unsigned)(col * ASB + 16 * kb);           // this lane's 8 consecutive k of pixel `col`
+
+    const int4 *my_items = items + (size_t)s * plan.item_cap;
+    int4 item_n = my_items[min(worker, plan.item_cap - 1)];      // (list is heaviest first)
+    for (int it = worker; it < n_it; it += workers) {
+        const int4 item = item_n;
+        item_n = my_items[min(it + workers, plan.item_cap - 1)];
+        const BlockGeo bg = unpack_block_geo((unsigned)item.x);
+        int lvH = plan.lv[0].H, lvW = plan.lv[0].W, lv_start = plan.lv[0].start;
+#pragma unroll
+        for (int k = 1; k < kMaxBinLevels; ++k)
+            if (k == bg.level) { lvH = plan.lv[k].H; lvW = plan.lv[k].W; lv_start = plan.lv[k].start; }
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
+        const float Hf = (float)lvH, Wf = (float)lvW;
+        const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
+        tr_f32x16 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+        // software pipeline over rounds of 64 records: the records are read three rounds ahead, their
+        // upstream rows two (into registers; staged into LDS once the current round's operands have been
+        // read).  Idle lanes of an item's last round (id -1) fetch from an offset outside the buffer: the
+        // load returns ZEROS without touching memory, which is what they have to stage (0 * Inf = NaN: in a
+        // dense product any row that happened to be fetched there could poison the block).
+        constexpr unsigned kNoRow = 0x80000000u;
+        auto fetch_rec = [&](int rr) -> int4 {
+            return rr + lane < item.z ? rec[rr + lane] : make_int4(-1, 0, 0, 0);
+        };
+        auto fetch_rows = [&](const int4 &r, u32x4 (&rows)[NPASS]) {
+            const unsigned off = r.x < 0 ? kNoRow : __umul24((unsigned)r.x >> plan.lp_bits, q_stride) + slice_off;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned oj = (unsigned)__shfl((int)off, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
+                rows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, oj, 0, 0);
+            }
+        };
+        auto stage_rows = [&](const u32x4 (&rows)[NPASS]) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(gs) + stage_off + ps * RPP * 64) = rows[ps];
+        };
+        int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
+        u32x4 grow_a[NPASS], grow_b[NPASS];
+        fetch_rows(rec_c, grow_a);
+        stage_rows(grow_a);
+        if (item.y + R < item.z) fetch_rows(rec_n, grow_a);
+        // one round: `next` holds the rows of round rr + R (staged at the end), `ahead` receives those of rr + 2 R
+        auto round = [&](int rr, const u32x4 (&next)[NPASS], u32x4 (&ahead)[NPASS]) {
+            const bool more = rr + R < item.z;     // wave-uniform
+            int4 rec_n3 = make_int4(-1, 0, 0, 0);
+            if (rr + 2 * R < item.z) {
+                fetch_rows(rec_n2, ahead);
+                rec_n3 = fetch_rec(rr + 3 * R);
+            }
+            // ---- lane = record: its <= 4 weights go to A^T[pixel][lane] as hi + lo bf16
+            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
+            float h_im, w_im;
+            {
+#pragma clang fp contract(off)                   // two roundings, as in locate()
+                h_im = y * Hf - 0.5f;
+                w_im = x * Wf - 0.5f;
+            }
+            const float yf = floorf(h_im), xf = floorf(w_im);
+            const float lh = h_im - yf, lw = w_im - xf, hh = 1.f - lh, hw = 1.f - lw;
+            const float ha = hh * a, la = lh * a;
+            const float w0 = ha * hw, w1 = ha * lw, w2 = la * hw, w3 = la * lw;
+            const unsigned hi01 = pack_bf16x2(w0, w1), hi23 = pack_bf16x2(w2, w3);
+            const unsigned lo01 = pack_bf16x2(w0 - __uint_as_float(hi01 << 16), w1 - __uint_as_float(hi01 & 0xffff0000u));
+            const unsigned lo23 = pack_bf16x2(w2 - __uint_as_float(hi23 << 16), w3 - __uint_as_float(hi23 & 0xffff0000u));
+            // byte offsets of the corners' rows / columns inside A^T, kBig when outside the block (idle lanes: all)
+            const int py = rec_c.x >= 0 ? (int)yf - oy : -2, px = (int)xf - ox;
+            const int r0 = (unsigned)py < (unsigned)bh ? __mul24(py, BW * ASB) : kBig;
+            const int r1 = (unsigned)(py + 1) < (unsigned)bh ? __mul24(py, BW * ASB) + BW * ASB : kBig;
+            const int c0 = (unsigned)px < (unsigned)bw ? __mul24(px, ASB) + 2 * lane : kBig;
+            const int c1 = (unsigned)(px + 1) < (unsigned)bw ? __mul24(px, ASB) + 2 * lane + ASB : kBig;
+            const int dump = kDump + 2 * lane;
+            const int slot[4] = {min(r0 + c0, dump), min(r0 + c1, dump), min(r1 + c0, dump), min(r1 + c1, dump)};
+            auto put = [&](int k, unsigned short v) {
+                *reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(at) + slot[k]) = v;
+            };
+            put(0, (unsigned short)(hi01 & 0xffffu)); put(1, (unsigned short)(hi01 >> 16));
+            put(2, (unsigned short)(hi23 & 0xffffu)); put(3, (unsigned short)(hi23 >> 16));
+            wave_lds_sync();
+            // ---- the product: 4 K-steps of 16 records per 32-channel block, hi term then lo term
+            tr_bf16x8 g[R / 16][NCB];
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const tr_bf16x8 p_hi = __builtin_bit_cast(
+                    tr_bf16x8, *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(at) + a_off + 32 * t));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const uint2 g0 = lds_read_tr16(gs, tr_off + cb * GPL + t * 1024);
+                    const uint2 g1 = lds_read_tr16(gs, tr_off + cb * GPL + t * 1024 + 256);
+                    g[t][cb] = __builtin_bit_cast(tr_bf16x8, u32x4{g0.x, g0.y, g1.x, g1.y});
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_hi, acc[cb], 0, 0, 0);
+                }
+            }
+            wave_lds_sync();                         // a wave's LDS operations execute in order
+            put(0, (unsigned short)(lo01 & 0xffffu)); put(1, (unsigned short)(lo01 >> 16));
+            put(2, (unsigned short)(lo23 & 0xffffu)); put(3, (unsigned short)(lo23 >> 16));
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const tr_bf16x8 p_lo = __builtin_bit_cast(
+                    tr_bf16x8, *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(at) + a_off + 32 * t));
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[t][cb], p_lo, acc[cb], 0, 0, 0);
+            }
+            wave_lds_sync();
+            // ---- clear this round's weights, stage the next round's rows (they have arrived)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) put(k, (unsigned short)0);
+            if (more) {
+                stage_rows(next);
+                rec_c = rec_n; rec_n = rec_n2; rec_n2 = rec_n3;
+            }
+            wave_lds_sync();
+        };
+        for (int rr = item.y; rr < item.z; rr += 2 * R) {       // (two rounds per trip: the row buffers swap roles, no copies)
+            round(rr, grow_a, grow_b);
+            if (rr + R >= item.z) break;
+            round(rr + R, grow_b, grow_a);
+        }
+        // ---- store.  Lane = pixel `col`; its registers hold channels 8 g + 4 kb + 0..3.
+        if (item.w < 0) {
+            // whole rows in the storage type: lanes l and l + 32 swap half of their packed pairs
+            // (v_permlane32_swap), so that each writes two 16-byte pieces (8 channels) of the pixel's row
+            const int py = col / BW, px = col % BW;
+            const bool live = py < bh && px < bw;
+            ST *dst = grad_value +
+                      (((size_t)b * S + lv_start + (size_t)(oy + py) * lvW + (ox + px)) * H + h) * C;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                unsigned pk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(acc[cb][2 * i], acc[cb][2 * i + 1]);
+                // pk[2 g], pk[2 g + 1]: channels 8 g + 4 kb + 0..3.  After swap(g = 0, g = 1) the lanes of
+                // kb = 0 hold channels 0-7 and those of kb = 1 channels 8-15; g = 2, 3 alike (+ 16).
+                u32x4 piece_lo, piece_hi;
+                {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+                    const auto s2 = __builtin_amdgcn_permlane32_swap(pk[4], pk[6], false, false);
+                    const auto s3 = __builtin_amdgcn_permlane32_swap(pk[5], pk[7], false, false);
+                    piece_lo = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    piece_hi = u32x4{s2[0], s3[0], s2[1], s3[1]};
+                }
+                const int c_lo = cb * 32 + 8 * kb, c_hi = cb * 32 + 16 + 8 * kb;
+                if (live && c_lo < C) *reinterpret_cast<u32x4 *>(dst + c_lo) = piece_lo;
+                if (live && c_hi < C) *reinterpret_cast<u32x4 *>(dst + c_hi) = piece_hi;
+            }
+        } else {
+            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + col) * C;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c = cb * 32 + 8 * g4 + 4 * kb;
+                    if (c < C)
+                        *reinterpret_cast<float4 *>(dst + c) =
+                            make_float4(acc[cb][4 * g4], acc[cb][4 * g4 + 1], acc[cb][4 * g4 + 2],
+                                        acc[cb][4 * g4 + 3]);
+                }
+        }
+    }
+}
+
+}  // namespace boxattn

@@ -40,6 +40,18 @@ struct BinPlan {
     BinLevel lv[kMaxBinLevels];
 };
 
+// Which slices (image, head) an XCD's accumulate workers take: CONSECUTIVE ones (1), i.e. with
+// two slices per XCD the heads 2j and 2j + 1 of one image -- the two 64-byte (bf16) halves of
+// every 128-byte line of grad_out they read and of grad_value they write then meet in ONE L2 --
+// or every 8th (0: head x of every image, the round-1 mapping: half lines in two L2s).
+#ifndef BOXATTN_TUNE_SLICE_MAP
+#define BOXATTN_TUNE_SLICE_MAP 1
+#endif
+__device__ __forceinline__ int slice_on_xcd(int xcd, int i, int per_xcd)
+{
+    return BOXATTN_TUNE_SLICE_MAP ? xcd * per_xcd + i : xcd + 8 * i;
+}
+
 // Blocks touched by the (valid part of the) 2x2 footprint of a sample: up to 2 block rows x 2
 // block columns, -1 for the unused candidates.  The valid rows of the footprint are exactly
 // {max(y0, 0), min(y0 + 1, H - 1)} (a point that passes the window test has y0 in [-1, H - 1]),

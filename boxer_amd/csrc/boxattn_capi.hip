@@ -41,7 +41,8 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
        kOptScanTail = 15,     // training forward: the block scans ride in the forward kernel's launch: 0 default (on), 1 off
        kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
-       kNumOpts = 16 };
+       kOptAccTr = 16,        // bf16 accumulate: 0 default (binned_accumulate_tr_kernel), 1 binned_accumulate_mfma_kernel
+       kNumOpts = 17 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
@@ -969,8 +970,8 @@ inline void launch_dense_binning(const float *loc, const Dims &d, const BinPlan 
     int *n_items = (int *)(ws + w.n_items), *offsets = (int *)(ws + w.offsets);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     const size_t gbytes = (size_t)ns * kDenseGroups * plan.nblk * sizeof(int);
-    zero_async(part, gbytes, st);
-    zero_async(ws + w.cursor, gbytes, st);
+    (void)zero_async(part, gbytes, st);
+    (void)zero_async(ws + w.cursor, gbytes, st);
     launch_dense_count(loc, dp, dense_bin(plan, part, nullptr, nullptr, nullptr, nullptr), st);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets, items, combos,
                        n_items, plan, part, kDenseGroups);
@@ -1070,6 +1071,25 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
     }
 }
 
+// the matrix-core accumulate of bf16 box attention: binned_accumulate_tr_kernel (32-bit row offsets:
+// grad_out below 2 GB) unless switched off, else binned_accumulate_mfma_kernel
+template <typename ST, int C>
+void launch_accumulate_mfma(const ST *grad_out, const Dims &d, const BinPlan &plan, int wg_per_slice, int ns8,
+                            const int4 *items, const int *n_items, const int *records, ST *grad_value,
+                            float *partials, hipStream_t st)
+{
+    if constexpr (std::is_same<ST, bf16_t>::value && (C == 16 || C == 32 || C == 64)) {
+        const size_t go_bytes = (size_t)d.B * d.Lq * d.H * C * sizeof(ST);
+        if (opt(kOptAccTr) != 1 && go_bytes < kAccTrMaxBytes && d.Lq < (1 << 24) && d.H * C * 2 < (1 << 24)) {
+            launch_accumulate_tr(C, grad_out, go_bytes, plan, d.S, d.H, d.Lq, items, n_items, records, grad_value,
+                                 partials, wg_per_slice, ns8, st);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((binned_accumulate_mfma_kernel<ST, C>), dim3(wg_per_slice, ns8), dim3(64), 0, st, grad_out,
+                       plan, d.S, d.H, d.Lq, items, n_items, records, grad_value, partials);
+}
+
 #define BOXATTN_TUNE_ACC_WG_CAP_DEFAULT 1024     // accumulate workgroups per slice at most (see BOXATTN_TUNE_ACC_WG_CAP)
 template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
@@ -1096,9 +1116,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
             const int wg_per_slice = std::min(BOXATTN_TUNE_ACC_WG_CAP_DEFAULT, std::max(1, plan.item_cap));
             {
                 ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
-                hipLaunchKernelGGL((binned_accumulate_mfma_kernel<ST, 4 * G>), dim3(wg_per_slice, ns8),
-                                   dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
-                                   records, grad_value, partials);
+                launch_accumulate_mfma<ST, 4 * G>(grad_out, d, plan, wg_per_slice, ns8, items, n_items, records,
+                                                  grad_value, partials, st);
             }
             {
                 ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
@@ -1155,9 +1174,8 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         bool done = false;
         if constexpr (kMfmaBuilt) {
             if (use_mfma) {
-                hipLaunchKernelGGL((binned_accumulate_mfma_kernel<ST, 4 * G>), dim3(wg_per_slice, ns8),
-                                   dim3(64), 0, st, grad_out, plan, d.S, d.H, d.Lq, items, n_items,
-                                   records, grad_value, partials);
+                launch_accumulate_mfma<ST, 4 * G>(grad_out, d, plan, wg_per_slice, ns8, items, n_items, records,
+                                                  grad_value, partials, st);
                 done = true;
             }
         }

@@ -1,6 +1,10 @@
-// Translation unit of the window-staged encoder kernels (boxattn_dense.h).  Built with
-// -fno-slp-vectorize (boxer_amd/_lib.py SOURCES).
+// Translation unit of the kernels that run float32 VALU arithmetic next to MFMAs: the window-staged
+// encoder kernels (boxattn_dense.h) and the matrix-core accumulate (boxattn_binned_tr.h).  Built with
+// -fno-slp-vectorize (boxer_amd/_lib.py SOURCES): a packed float32 instruction
+// (v_pk_mul_f32 / v_pk_fma_f32, which the SLP vectoriser makes of neighbouring scalar operations) issued
+// while an MFMA of the same wave is completing was seen to return wrong values on MI355X.
 #include "boxattn_dense.h"
+#include "boxattn_binned_tr.h"
 
 namespace boxattn {
 
@@ -41,6 +45,22 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
         BOXATTN_DENSE_PG(1) BOXATTN_DENSE_PG(2) BOXATTN_DENSE_PG(3) BOXATTN_DENSE_PG(4)
     }
 #undef BOXATTN_DENSE_PG
+}
+
+void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
+                          int H, int Lq, const int4 *items, const int *n_items, const int *records,
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, hipStream_t st)
+{
+#define BOXATTN_ACC_TR(C_)                                                                              \
+    case C_:                                                                                            \
+        hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
+                           grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, \
+                           grad_value, partials);                                                       \
+        break;
+    switch (C) {
+        BOXATTN_ACC_TR(16) BOXATTN_ACC_TR(32) BOXATTN_ACC_TR(64)
+    }
+#undef BOXATTN_ACC_TR
 }
 
 }  // namespace boxattn

@@ -103,4 +103,12 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
                             float *grad_attn, unsigned value_bytes, hipStream_t st,
                             const CombineTail &tail, const DenseBin &bin);
 
+// The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
+// because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per
+// head, grad_out below 2 GB (32-bit row offsets, and an out-of-range offset for idle lanes).
+constexpr size_t kAccTrMaxBytes = (size_t)1 << 31;
+void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
+                          int H, int Lq, const int4 *items, const int *n_items, const int *records,
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, hipStream_t st);
+
 }  // namespace boxattn
