@@ -79,6 +79,7 @@ _GRID_SIGNATURES = {
     "boxattn_grid_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp],
 }
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "boxattn_set_option",
+           "boxattn_set_debug_buffer",
            "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16", *sorted(_POINTWISE_SIGNATURES),
            "boxattn_fwd_grid_f32", "boxattn_fwd_grid_bf16", "boxattn_bwd_ws_grid_f32",
            "boxattn_bwd_ws_grid_bf16",

@@ -1606,7 +1606,8 @@ const char *boxattn_build_info(void)
 {
     return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
            " | kernels: generic{f32,f64,bf16}, gather{f32 4ch/lane, bf16 8ch/lane} C={16,32,64}, "
-           "binned-bwd{f32,bf16}, box-grid{f32} | abi 6";
+           "binned-bwd{f32,bf16; bf16 accumulate on MFMA}, window-staged encoder point gradients{bf16}, "
+           "box-grid{f32} | abi 6";
 }
 
 int boxattn_profile_begin(void)

@@ -214,40 +214,78 @@ __device__ __forceinline__ unsigned quad_bcast_u32(unsigned v, int t)      // t 
     }
 }
 
-// The four corner sums S_k = sum_c g_c v_k,c of one sample point: from the staged window where its
-// footprint lies inside, else from global memory (`slow`, decided per lane, entered per wave).
-__device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const DenseWinPos &o,
+// A sample point as the kernels need it (locate() of boxattn_device.h without the per-corner flags:
+// the flag algebra is done on integers below -- lane masks combined in scalar registers were a third
+// of this kernel's instructions, and scalar instructions are not free).
+struct DensePoint {
+    int y0, x0;              // top-left corner of the footprint, in [-1, H - 1] x [-1, W - 1] (0, 0 if !inside)
+    float lh, lw, hh, hw;
+    bool inside;             // the reference's window test (the levels of a dense plan are never empty)
+};
+__device__ __forceinline__ DensePoint dense_locate(float x, float y, int H, int W)
+{
+    DensePoint s;
+    float h_im, w_im;
+    {
+#pragma clang fp contract(off)                   // two roundings, as in locate()
+        h_im = y * (float)H - 0.5f;
+        w_im = x * (float)W - 0.5f;
+    }
+    s.inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+    const float hs = s.inside ? h_im : 0.f, ws = s.inside ? w_im : 0.f;   // NaN / outside: finite index arithmetic
+    const float hf = floorf(hs), wf = floorf(ws);
+    s.y0 = (int)hf;
+    s.x0 = (int)wf;
+    s.lh = hs - hf;
+    s.lw = ws - wf;
+    s.hh = 1.f - s.lh;
+    s.hw = 1.f - s.lw;
+    return s;
+}
+
+// The four corner sums S_k = sum_c g_c v_k,c of one sample point: from the staged window if the part of
+// its footprint that lies inside the map lies inside the window, else from global memory (`slow`,
+// decided per lane, entered per wave).  Corners outside the map give exactly 0.
+__device__ __forceinline__ void dense_corner_sums(const DensePoint &s, const DenseMap &T, const DenseWinPos &o,
                                                   const unsigned char *lds, const unsigned (&gw)[16],
                                                   const bf16_t *value, unsigned row0, int H, int h, bool vq,
                                                   int lane_p, float (&sk)[4])
 {
     constexpr int C = 32;
     const int rows = o.rows(), cols = o.cols();
-    const int r0 = s.y0 - o.y0, c0 = s.x0 - o.x0;                  // window coordinates of corner 1
-    const bool in_r0 = r0 >= 0 && r0 < rows, in_r1 = r0 + 1 >= 0 && r0 + 1 < rows;
-    const bool in_c0 = c0 >= 0 && c0 < cols, in_c1 = c0 + 1 >= 0 && c0 + 1 < cols;
-    const bool in[4] = {in_r0 && in_c0, in_r0 && in_c1, in_r1 && in_c0, in_r1 && in_c1};
-    const bool slow = vq && ((s.ok[0] && !in[0]) || (s.ok[1] && !in[1]) || (s.ok[2] && !in[2]) ||
-                             (s.ok[3] && !in[3]));
-    const bool hit = vq && ((s.ok[0] && in[0]) || (s.ok[1] && in[1]) || (s.ok[2] && in[2]) || (s.ok[3] && in[3]));
-    if (rows > 0 && __builtin_amdgcn_ballot_w64(hit) != 0ull) {    // wave-uniform: some corner is staged
-        const int rr0 = min(max(r0, 0), rows - 1), rr1 = min(max(r0 + 1, 0), rows - 1);
-        const int cc0 = min(max(c0, 0), cols - 1), cc1 = min(max(c0 + 1, 0), cols - 1);
-        const int row0s = o.off() + __mul24(rr0, o.pitch()), row1s = o.off() + __mul24(rr1, o.pitch());
-        const int slot[4] = {row0s + cc0, row0s + cc1, row1s + cc0, row1s + cc1};
+    const int Hm1 = T.H - 1, Wm1 = T.W - 1;
+    // all-ones where the corner counts: inside the map (row y0 unless y0 == -1, row y0 + 1 unless y0 == H - 1,
+    // columns alike) and the point inside the window test
+    const unsigned mi = s.inside ? 0xffffffffu : 0u;
+    const unsigned mr0 = ~(unsigned)(s.y0 >> 31) & mi, mr1 = (unsigned)((s.y0 - Hm1) >> 31) & mi;
+    const unsigned mc0 = ~(unsigned)(s.x0 >> 31), mc1 = (unsigned)((s.x0 - Wm1) >> 31);
+    const unsigned m[4] = {mr0 & mc0, mr0 & mc1, mr1 & mc0, mr1 & mc1};
+    // rows / columns of the map the footprint needs, and how far they are inside the staged window
+    // (negative: something is missing; an unstaged level has rows == 0, so d < 0 for every point)
+    const int ra = max(s.y0, 0), rb = min(s.y0 + 1, Hm1), ca = max(s.x0, 0), cb = min(s.x0 + 1, Wm1);
+    const int d = min(min(ra - o.y0, o.y0 + rows - 1 - rb), min(ca - o.x0, o.x0 + cols - 1 - cb));
+    const bool act = vq && s.inside;
+    const bool slow = act && d < 0, fast = act && d >= 0;
+    if (__builtin_amdgcn_ballot_w64(fast) != 0ull) {               // wave-uniform: somebody reads the window
+        // (lanes that do not: clamped slots, results masked or overwritten below)
+        const int pitchb = __mul24(o.pitch(), kDenseSlotBytes), offb = __mul24(o.off(), kDenseSlotBytes);
+        const int rr0 = min(max(s.y0 - o.y0, 0), rows - 1), rr1 = min(max(s.y0 + 1 - o.y0, 0), rows - 1);
+        const int cc0 = min(max(s.x0 - o.x0, 0), cols - 1), cc1 = min(max(s.x0 + 1 - o.x0, 0), cols - 1);
+        const int rowb0 = offb + __mul24(rr0, pitchb), rowb1 = offb + __mul24(rr1, pitchb);
+        const int colb0 = __mul24(cc0, kDenseSlotBytes), colb1 = __mul24(cc1, kDenseSlotBytes);
+        const int slot[4] = {rowb0 + colb0, rowb0 + colb1, rowb1 + colb0, rowb1 + colb1};
         // two corners at a time: 8 LDS reads in flight, then the 32 dot products; the rows of corners
-        // that do not count (outside the map or the window) are read from a clamped slot and masked
-        // out bitwise -- a select on the finished sum lets the compiler put every corner under its own
-        // branch (reads, wait, dots, four times in a row), a multiplication by 0 would let a non-finite
-        // value of an unrelated pixel through
+        // that do not count are read from a clamped slot and masked out bitwise -- a select on the
+        // finished sum lets the compiler put every corner under its own branch (reads, wait, dots, four
+        // times in a row), a multiplication by 0 would let a non-finite value of an unrelated pixel through
 #pragma unroll
         for (int k0 = 0; k0 < 4; k0 += 2) {
             unsigned va[16], vb[16];
-            dense_load_row(lds + __mul24(slot[k0], kDenseSlotBytes), va);
-            dense_load_row(lds + __mul24(slot[k0 + 1], kDenseSlotBytes), vb);
+            dense_load_row(lds + slot[k0], va);
+            dense_load_row(lds + slot[k0 + 1], vb);
             const float da = dense_dot_row(gw, va), db = dense_dot_row(gw, vb);
-            sk[k0] = __uint_as_float(__float_as_uint(da) & ((s.ok[k0] && in[k0]) ? 0xffffffffu : 0u));
-            sk[k0 + 1] = __uint_as_float(__float_as_uint(db) & ((s.ok[k0 + 1] && in[k0 + 1]) ? 0xffffffffu : 0u));
+            sk[k0] = __uint_as_float(__float_as_uint(da) & m[k0]);
+            sk[k0 + 1] = __uint_as_float(__float_as_uint(db) & m[k0 + 1]);
         }
     } else {
 #pragma unroll
@@ -263,10 +301,12 @@ __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             gch[i] = p == 0 ? gw[i] : p == 1 ? gw[4 + i] : p == 2 ? gw[8 + i] : gw[12 + i];
+        const int pra = __mul24(ra, T.W), prb = __mul24(rb, T.W);
+        const int pix[4] = {pra + ca, pra + cb, prb + ca, prb + cb};          // (clamped into the map: always a valid row)
         unsigned off[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            off[k] = (unsigned)(((row0 + (unsigned)s.pix[k]) * H + h) * (C * 2)) + (unsigned)p * 16u;
+            off[k] = (unsigned)(((row0 + (unsigned)pix[k]) * H + h) * (C * 2));
         // two points of the quad at a time: their 8 row pieces are requested together and unconditionally
         // (the offsets are always inside the map) -- one point at a time, each under its own "anyone
         // slow?" branch, a level was four memory round trips in a row (s_memtime: 9 000 cycles a level)
@@ -277,9 +317,9 @@ __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    // (my own offset already carries my chunk: take lane t's row, keep my 16-byte piece)
-                    const unsigned o = quad_bcast_u32(off[k] - (unsigned)p * 16u, t0 + u) + (unsigned)p * 16u;
-                    v[u][k] = *reinterpret_cast<const dense_u32x4 *>(reinterpret_cast<const char *>(value) + o);
+                    // lane t's row, my 16-byte piece of it
+                    const unsigned oo = quad_bcast_u32(off[k], t0 + u) + (unsigned)p * 16u;
+                    v[u][k] = *reinterpret_cast<const dense_u32x4 *>(reinterpret_cast<const char *>(value) + oo);
                 }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -287,16 +327,16 @@ __device__ __forceinline__ void dense_corner_sums(const Sample<float> &s, const 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned vw[4] = {v[u][k].x, v[u][k].y, v[u][k].z, v[u][k].w};
-                    float d = 0.f;
+                    float dd = 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gch[i]),
-                                                            __builtin_bit_cast(bf16x2_t, vw[i]), d, false);
-                    part[k] = group_sum<4>(d);
+                        dd = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, gch[i]),
+                                                            __builtin_bit_cast(bf16x2_t, vw[i]), dd, false);
+                    part[k] = group_sum<4>(dd);
                 }
                 if (p == t0 + u && slow) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sk[k] = s.ok[k] ? part[k] : 0.f;
+                    for (int k = 0; k < 4; ++k) sk[k] = __uint_as_float(__float_as_uint(part[k]) & m[k]);
                 }
             }
         }
@@ -484,9 +524,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const DenseMap T = hot.lv[l];
-        const Sample<float> s = locate<float>(xy[l].x, xy[l].y, T.H, T.W);
+        const DensePoint s = dense_locate(xy[l].x, xy[l].y, T.H, T.W);
         float sk[4];
-        dense_corner_sums(s, win[l], win_lds, gw, value, t.b * (unsigned)hot.S + (unsigned)T.start, H, h, vq, p, sk);
+        dense_corner_sums(s, T, win[l], win_lds, gw, value, t.b * (unsigned)hot.S + (unsigned)T.start, H, h, vq, p, sk);
         const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
         const float gs_ = w1 * sk[0] + w2 * sk[1] + w3 * sk[2] + w4 * sk[3];
         const float gx_ = (float)T.W * a[l] * (s.hh * (sk[1] - sk[0]) + s.lh * (sk[3] - sk[2]));

@@ -342,8 +342,26 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *  10  binned backward: records per work item (multiple of 64; default: from the number of sample
  *      points, 128 ... 1024).  Set it before boxattn_bwd_workspace_bytes: the workspace layout
  *      depends on it.
+ *  11  window-staged point-gradient kernel of the encoder case (bf16 box attention, Lq == S, C = 32,
+ *      2x2 points, <= 4 levels): 0 library default (on), 1 off (row-gather kernel), 2 on
+ *  12  ... margin of its staged windows for the predicted box offsets, in tenths of a quarter of the
+ *      expected box (0 = default 25); 13 ... expected box size in pixels of the query's own level
+ *      (0 = default 4, BoxeR's reference windows).  Placement only: results do not depend on them.
+ *  14  ... the window-staged kernels also count and write the bin records (no bin_kernel passes):
+ *      0 / 1 off (default: measured no faster), 2 on.  Set before *_fwd_train_* / the backward.
+ *  15  training forward: the backward's two scan kernels ride in the forward kernel's launch:
+ *      0 default (on), 1 off (stand-alone bin_scan_a_kernel / bin_scan_kernel)
+ *  16  matrix-core accumulate of bf16 box attention: 0 default (binned_accumulate_tr_kernel: rows read
+ *      with the transposing LDS read), 1 the round-1/2 kernel (binned_accumulate_mfma_kernel)
  */
 int boxattn_set_option(int key, int value);
+
+/*
+ * Debugging aid of the window-staged kernels: builds with -DBOXATTN_DENSE_DEBUG=1/2 write per-point
+ * corner sums / per-wave time stamps to this device buffer (tools/gpu_dense_debug.py,
+ * tools/gpu_dense_trace.py).  Ignored by regular builds.
+ */
+void boxattn_set_debug_buffer(float *device_buffer);
 
 /*
  * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the
