@@ -237,6 +237,32 @@ def test_box_backward_algorithms(cfg, dtype, variant):
     close(ga, want[2], torch.float32, "grad_attn")
 
 
+OPT_ACC_TR = 16         # boxattn_set_option: 0 binned_accumulate_tr_kernel (default), 1 binned_accumulate_mfma_kernel
+
+
+@pytest.mark.parametrize("cfg", FAST_CFGS + [SEEDED[7]], ids=[str(i) for i in range(len(FAST_CFGS) + 1)])
+def test_both_matrix_core_accumulate_kernels(cfg):
+    """bf16 grad_value from the two accumulate kernels (rows read with the transposing LDS read /
+    rows transposed in registers; C = 16, 32, 64): both against the oracle, and against each other
+    to float32 rounding of the weights (the order of the products inside a weight differs)."""
+    from boxer_amd import _lib
+    g = _seeded(*cfg, seed=23, lo=-0.2, hi=1.2)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                g["grad_out"])
+    res = {}
+    for mode in (0, 1):
+        old = _lib.load().boxattn_set_option(OPT_ACC_TR, mode)
+        try:
+            res[mode] = run_box(g, torch.bfloat16, "binned")[1]
+        finally:
+            _lib.load().boxattn_set_option(OPT_ACC_TR, old)
+        close(res[mode], want[0], torch.bfloat16, "grad_value (accumulate kernel %d)" % mode)
+    a, b = res[0].float(), res[1].float()
+    scale = max(1.0, b.abs().max().item())
+    # (one bf16 ulp where a sum lands on a rounding boundary)
+    assert (a - b).abs().max().item() <= 2.0 ** -7 * scale
+
+
 @pytest.mark.parametrize("variant", ["atomic", "binned"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", FAST_CFGS[:5], ids=[str(i) for i in range(5)])
