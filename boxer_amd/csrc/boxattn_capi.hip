@@ -42,7 +42,8 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptScanTail = 15,     // training forward: the block scans ride in the forward kernel's launch: 0 default (on), 1 off
        kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
        kOptAccTr = 16,        // bf16 accumulate: 0 default (binned_accumulate_tr_kernel), 1 binned_accumulate_mfma_kernel
-       kNumOpts = 17 };
+       kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 / 1 off, 2 on
+       kNumOpts = 18 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
@@ -323,6 +324,8 @@ int launch_fwd_tile(const ST *value, const float *loc, const float *attn, const 
 }
 
 // ------------------------------------------------------------------------------ forward
+inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p);
+
 template <typename ST, bool INST>
 int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                const typename Storage<ST>::compute *loc,
@@ -350,6 +353,15 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     if constexpr (!std::is_same<ST, double>::value) {
         if (fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out,
                         out)) {
+            if constexpr (!INST && std::is_same<ST, bf16_t>::value) {     // encoder case: window-staged matrix-core forward
+                DensePlan dp;
+                if (opt(kOptDenseFwd) == 2 && shapes_host && lsi_host && aligned(value, 16) && aligned(loc, 8) &&
+                    make_dense_plan(d, shapes_host, lsi_host, dp)) {
+                    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+                    launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)), st);
+                    return finish();
+                }
+            }
             if constexpr (!INST) {          // encoder case: LDS-staged value windows
                 TilePlan tp;
                 const TileShape ts = tile_shape<ST>();
@@ -918,8 +930,11 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             w.ax = (int)std::lround(kDenseTile * rx * 65536.0f); w.bx = (int)std::floor((0.5f * rx - 0.5f - mx) * 65536.0f);
             w.ay = (int)std::lround(kDenseTile * ry * 65536.0f); w.by = (int)std::floor((0.5f * ry - 0.5f - my) * 65536.0f);
             if (rx > 8.0f || ry > 8.0f) { w.ax = w.ay = 0; }      // (not staged anyway; keeps tx * ax inside 31 bits)
-            const int pitch = cols + 2;             // slots of neighbouring rows start 2 bank groups apart
-            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots;
+#ifndef BOXATTN_DENSE_PITCH_PAD
+#define BOXATTN_DENSE_PITCH_PAD 2
+#endif
+            const int pitch = cols + BOXATTN_DENSE_PITCH_PAD;   // slots of neighbouring rows start 2 bank groups apart
+            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots - 1;   // (the last slot is the forward's zero row)
             w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, pitch, used);
             if (fits) used += rows * pitch;
         }

@@ -101,8 +101,12 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
     for (int l = 0; l < L; ++l) {
         hot.lv[l] = DenseMap{pl.lv[l].H, pl.lv[l].W, pl.lv[l].start};
         n_all[l] = pl.lv[l].n_all;
+        // (opaque to the compiler from here on: it otherwise sinks these scalar loads to their first use,
+        // one round trip per level in the middle of the row requests)
+        asm volatile("" : "+s"(hot.lv[l].H), "+s"(hot.lv[l].W), "+s"(hot.lv[l].start));
     }
     hot.H = pl.H; hot.Lq = pl.Lq; hot.S = pl.S;
+    asm volatile("" : "+s"(hot.H), "+s"(hot.Lq), "+s"(hot.S));
     DenseTileId t;
     const unsigned x = block & 7u;
     unsigned j, h;
@@ -125,6 +129,7 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
 #pragma unroll
     for (int l = 0; l < L; ++l) wrow[l] = pl.win[lqc][l];
     Q = DenseMap{q.H, q.W, q.start};
+    asm volatile("" : "+s"(Q.H), "+s"(Q.W), "+s"(Q.start));      // (loaded with the batch, not at first use)
     unsigned tr, ty, tx;
     divmod_magic(ti, (unsigned)q.ntiles, q.mag_ntiles, t.b, tr);
     divmod_magic(tr, (unsigned)q.ntx, q.mag_ntx, ty, tx);

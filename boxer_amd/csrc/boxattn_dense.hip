@@ -5,6 +5,7 @@
 // while an MFMA of the same wave is completing was seen to return wrong values on MI355X.
 #include "boxattn_dense.h"
 #include "boxattn_binned_tr.h"
+#include "boxattn_dense_fwd.h"
 
 namespace boxattn {
 
@@ -45,6 +46,21 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
         BOXATTN_DENSE_PG(1) BOXATTN_DENSE_PG(2) BOXATTN_DENSE_PG(3) BOXATTN_DENSE_PG(4)
     }
 #undef BOXATTN_DENSE_PG
+}
+
+void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
+                      const DensePlan &dp, unsigned value_bytes, hipStream_t st)
+{
+    const unsigned blocks = dense_blocks(dp);
+#define BOXATTN_DENSE_FWD(LV_)                                                                       \
+    case LV_:                                                                                        \
+        hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(blocks), dim3(256), 0, st, value, loc, attn, out, dp, \
+                           value_bytes);                                                             \
+        break;
+    switch (dp.L) {
+        BOXATTN_DENSE_FWD(1) BOXATTN_DENSE_FWD(2) BOXATTN_DENSE_FWD(3) BOXATTN_DENSE_FWD(4)
+    }
+#undef BOXATTN_DENSE_FWD
 }
 
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,

@@ -15,7 +15,10 @@ constexpr int kDenseSub = 4;               // ... = 2x2 sub-tiles of 4x4 queries
 constexpr int kDenseWinMax = 16;           // window rows / columns at most (one wave-load per window row)
 constexpr int kDenseSlotBytes = 80;        // one staged pixel: 64 bytes of bf16 channels + 16 bytes of padding
                                            // (bank = 20 slot + 4 chunk mod 64: 16 consecutive slots, 16 bank groups)
-constexpr int kDenseSlots = 480;           // staged pixels per workgroup (38 400 bytes)
+#ifndef BOXATTN_DENSE_SLOTS
+#define BOXATTN_DENSE_SLOTS 480
+#endif
+constexpr int kDenseSlots = BOXATTN_DENSE_SLOTS;   // staged pixels per workgroup (480: 38 400 bytes)
 
 struct DenseLevel {
     int H, W, start;         // map size, first row of the level in `value`
@@ -102,6 +105,10 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
                             const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
                             float *grad_attn, unsigned value_bytes, hipStream_t st,
                             const CombineTail &tail, const DenseBin &bin);
+
+// out of bf16 box attention on a query grid (boxattn_dense_fwd.h)
+void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
+                      const DensePlan &dp, unsigned value_bytes, hipStream_t st);
 
 // The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
 // because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per
