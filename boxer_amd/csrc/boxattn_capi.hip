@@ -42,8 +42,11 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptScanTail = 15,     // training forward: the block scans ride in the forward kernel's launch: 0 default (on), 1 off
        kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
        kOptAccTr = 16,        // bf16 accumulate: 0 default (binned_accumulate_tr_kernel), 1 binned_accumulate_mfma_kernel
-       kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 / 1 off, 2 on
+       kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (BOXATTN_DENSE_FWD_DEFAULT), 1 off, 2 on
        kNumOpts = 18 };
+#ifndef BOXATTN_DENSE_FWD_DEFAULT
+#define BOXATTN_DENSE_FWD_DEFAULT 2      // 2: on where eligible, 0: off
+#endif
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 
@@ -355,10 +358,14 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                         out)) {
             if constexpr (!INST && std::is_same<ST, bf16_t>::value) {     // encoder case: window-staged matrix-core forward
                 DensePlan dp;
-                if (opt(kOptDenseFwd) == 2 && shapes_host && lsi_host && aligned(value, 16) && aligned(loc, 8) &&
+                if (opt(kOptDenseFwd) != 1 && BOXATTN_DENSE_FWD_DEFAULT + opt(kOptDenseFwd) >= 2 && shapes_host &&
+                    lsi_host && aligned(value, 16) && aligned(out, 16) && aligned(loc, 8) &&
                     make_dense_plan(d, shapes_host, lsi_host, dp)) {
+                    const bool tail = scan_tail && scan_tail->n_wg > 0;
                     ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
-                    launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)), st);
+                    launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)),
+                                     tail ? scan_tail : nullptr, st);
+                    if (tail && scan_tail_taken) *scan_tail_taken = true;
                     return finish();
                 }
             }

@@ -49,13 +49,15 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
 }
 
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, hipStream_t st)
+                      const DensePlan &dp, unsigned value_bytes, const ScanTail *scan_tail, hipStream_t st)
 {
     const unsigned blocks = dense_blocks(dp);
+    const ScanTail sct = scan_tail ? *scan_tail : ScanTail{};
+    const unsigned lead = scan_tail ? (unsigned)(sct.plan.n_slices * kScanSub) : 0u;    // in FRONT of the grid
 #define BOXATTN_DENSE_FWD(LV_)                                                                       \
     case LV_:                                                                                        \
-        hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(blocks), dim3(256), 0, st, value, loc, attn, out, dp, \
-                           value_bytes);                                                             \
+        hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(blocks + lead), dim3(256), 0, st, value, loc, attn, out, \
+                           dp, value_bytes, lead, sct);                                              \
         break;
     switch (dp.L) {
         BOXATTN_DENSE_FWD(1) BOXATTN_DENSE_FWD(2) BOXATTN_DENSE_FWD(3) BOXATTN_DENSE_FWD(4)

@@ -107,8 +107,9 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
                             const CombineTail &tail, const DenseBin &bin);
 
 // out of bf16 box attention on a query grid (boxattn_dense_fwd.h)
+struct ScanTail;             // boxattn_binned.h: the backward's block scans as extra workgroups (training forward), or null
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, hipStream_t st);
+                      const DensePlan &dp, unsigned value_bytes, const ScanTail *scan_tail, hipStream_t st);
 
 // The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
 // because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per

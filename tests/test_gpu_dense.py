@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 OPT_DENSE = 11          # boxattn_set_option key: 0 library default, 1 dense kernels off, 2 on
 OPT_DENSE_FILL = 14     # ... the window-staged kernels also count and write the bin records: 2 on (default off)
+OPT_DENSE_FWD = 17      # window-staged matrix-core forward: 0 library default (on), 1 off (fwd2_kernel), 2 on
 
 
 def _lib():
@@ -31,6 +32,16 @@ def dense_switch():
     old = lib.boxattn_set_option(OPT_DENSE, 0)
     yield lambda on: lib.boxattn_set_option(OPT_DENSE, 2 if on else 1)
     lib.boxattn_set_option(OPT_DENSE, old)
+
+
+@pytest.fixture(params=[True, False], ids=["staged_fwd", "gather_fwd"])
+def forward_kernel(request):
+    """Both forward kernels of the encoder case: the window-staged matrix-core forward (default) and the
+    row-gather kernel (fwd2_kernel)."""
+    lib = _lib()
+    old = lib.boxattn_set_option(OPT_DENSE_FWD, 2 if request.param else 1)
+    yield request.param
+    lib.boxattn_set_option(OPT_DENSE_FWD, old)
 
 
 @pytest.fixture(params=[False, True], ids=["bin_kernel", "own_binning"])
@@ -92,7 +103,7 @@ LEVELS = {
 
 @pytest.mark.parametrize("family", ["model", "test", "mixed", "border"])
 @pytest.mark.parametrize("lv", sorted(LEVELS))
-def test_dense_kernels_match_oracle(lv, family, dense_switch, binning):
+def test_dense_kernels_match_oracle(lv, family, dense_switch, binning, forward_kernel):
     dense_switch(True)
     inp = make_case(LEVELS[lv], family)
     out, grads = run(inp)
@@ -101,7 +112,7 @@ def test_dense_kernels_match_oracle(lv, family, dense_switch, binning):
 
 
 @pytest.mark.parametrize("H", [1, 4, 6, 8])
-def test_dense_kernels_head_counts(H, dense_switch, binning):
+def test_dense_kernels_head_counts(H, dense_switch, binning, forward_kernel):
     dense_switch(True)
     inp = make_case(LEVELS["4lv"], "mixed", H=H, B=1, seed=3)
     out, grads = run(inp, with_plan=False)
@@ -139,10 +150,52 @@ def test_dense_kernels_skipped_points_write_zeros(dense_switch):
         assert worst <= tol, (name, worst)
 
 
+def test_staged_and_gather_forward_agree():
+    """Same call through both forward kernels at the headline shape, both input families: equal to one bf16
+    ulp (float32 sums in another order; the staged kernel's weights as hi + lo bf16 terms, 2^-17)."""
+    from boxer_amd import ops
+    lib = _lib()
+    for family in ("model", "test"):
+        inp = bench.make_inputs("C2", torch.bfloat16, "cuda", family=family, batch=1, seed=4)
+        v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
+        outs = {}
+        for mode in (1, 2):
+            old = lib.boxattn_set_option(OPT_DENSE_FWD, mode)
+            try:
+                outs[mode] = ops.box_attn_forward(v, sh, ls, loc, attn, 64).float()
+                torch.cuda.synchronize()
+            finally:
+                lib.boxattn_set_option(OPT_DENSE_FWD, old)
+        scale = max(1e-6, outs[1].abs().max().item())
+        assert (outs[1] - outs[2]).abs().max().item() <= 2.0 ** -7 * scale, family
+
+
+def test_staged_forward_ignores_value_where_no_point_counts():
+    """A non-finite value row that no counted corner touches must not reach `out`: corners outside the map
+    read the zero row, not a clamped neighbour times a zero weight (0 * Inf = NaN)."""
+    from boxer_amd import ops
+    lib = _lib()
+    inp = make_case(LEVELS["2lv"], "border", seed=9)
+    v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
+    old = lib.boxattn_set_option(OPT_DENSE_FWD, 2)
+    try:
+        ref = ops.box_attn_forward(v, sh, ls, loc, attn, 64).float()
+        # all sampling locations of query 5 far outside: it reads nothing
+        loc2 = loc.clone()
+        loc2[:, 5] = 9.0
+        out = ops.box_attn_forward(v.clone().fill_(float("inf")), sh, ls, loc2, attn, 64).float()
+        torch.cuda.synchronize()
+    finally:
+        lib.boxattn_set_option(OPT_DENSE_FWD, old)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(out[:, 5], torch.zeros_like(out[:, 5]))
+
+
 OPT_SCAN_TAIL = 15      # 0 default (the block scans ride in the forward kernel's launch), 1 off
 
 
-def test_scans_inside_the_forward_launch_match_the_scan_kernels():
+@pytest.mark.parametrize("fwd", [2, 1], ids=["staged_fwd", "gather_fwd"])
+def test_scans_inside_the_forward_launch_match_the_scan_kernels(fwd):
     """The training forward runs the backward's two scan kernels as extra workgroups of the forward
     kernel (bin_scan_tail_body: a ticket per slice, the last workgroup scans the blocks).  Same plan as
     the stand-alone kernels -- compared through what the backward makes of it -- for both storage
@@ -150,6 +203,7 @@ def test_scans_inside_the_forward_launch_match_the_scan_kernels():
     up as a wrong bin offset sooner or later)."""
     from boxer_amd import ops
     lib = _lib()
+    old_fwd = lib.boxattn_set_option(OPT_DENSE_FWD, fwd)
     for dtype in (torch.bfloat16, torch.float32):
         inp = bench.make_inputs("C2", dtype, "cuda", family="model", batch=2, seed=1)
         v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
@@ -172,3 +226,4 @@ def test_scans_inside_the_forward_launch_match_the_scan_kernels():
             err = (gv.float() - ref[1].float()).abs().max().item()
             # (the order of the records inside a bin, hence the float32 summation order, may differ)
             assert err <= (1e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, ref[1].float().abs().max().item())
+    lib.boxattn_set_option(OPT_DENSE_FWD, old_fwd)

@@ -1099,7 +1099,14 @@ def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, 
     out, grid = res
     want_grid = ops.box_grid_forward(ref, off, kidx, vr, angle_mode)
     assert torch.equal(grid, want_grid)
-    assert torch.equal(out, ops.box_attn_forward(value, shapes, lsi, want_grid, attn, 64))
+    plain = ops.box_attn_forward(value, shapes, lsi, want_grid, attn, 64)
+    if dtype == torch.bfloat16:
+        # bf16 encoder shapes: box_attn_forward takes the window-staged matrix-core forward, the fused call
+        # the row-gather kernel -- the same float32 sums in another order: one bf16 ulp
+        err = (out.float() - plain.float()).abs().max().item()
+        assert err <= 2.0 ** -7 * max(1.0, plain.float().abs().max().item())
+    else:
+        assert torch.equal(out, plain)
     fused = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr,
                                            angle_mode, need_ref_grad=True)
     assert fused is not None, "the fused backward should take this shape"
