@@ -36,6 +36,19 @@
 
 namespace boxattn {
 
+// lanes (0, 1, 2, 3) of every quad <- lanes (2 u, 2 u, 2 u + 1, 2 u + 1)
+__device__ __forceinline__ unsigned quad_pairs_u32(unsigned v, int u)       // u is a constant after unrolling
+{
+    return u == 0 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x50, 0xF, 0xF, true)      // quad_perm [0,0,1,1]
+                  : (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xFA, 0xF, 0xF, true);     // quad_perm [2,2,3,3]
+}
+// lanes (0, 1, 2, 3) <- lanes (2 u, 2 u + 1, 2 u, 2 u + 1)
+__device__ __forceinline__ unsigned quad_evenodd_u32(unsigned v, int u)
+{
+    return u == 0 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x44, 0xF, 0xF, true)      // quad_perm [0,1,0,1]
+                  : (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xEE, 0xF, 0xF, true);     // quad_perm [2,3,2,3]
+}
+
 typedef short fwd_i16x4 __attribute__((ext_vector_type(4)));
 typedef float fwd_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -124,17 +137,24 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
         const unsigned lo01 = pack_bf16x2(wk[0] - __uint_as_float(hi01 << 16), wk[1] - __uint_as_float(hi01 & 0xffff0000u));
         const unsigned lo23 = pack_bf16x2(wk[2] - __uint_as_float(hi23 << 16), wk[3] - __uint_as_float(hi23 & 0xffff0000u));
         const int dj = (jc & 1) * kDenseSlotBytes + (jc >> 1) * pitchb - kBias;       // my corner relative to the packed slot
-        if (rows > 0) {                                            // (wave-uniform: the level is staged)
+        // A operand: lane i of a quad holds row i -- rows 0, 2: the hi terms, rows 1, 3: the lo terms of the point
+        // the quad is working on.  Arranged once per level so that ONE quad permute per register and point
+        // delivers it: z_[0] = {hi(0), lo(0), hi(1), lo(1)} by lane, z_[1] = {hi(2), lo(2), hi(3), lo(3)}
+        // (bitwise merges, not ?: -- the compiler turns a select of two DPP moves into a branch and runs each move
+        // with half of the lanes switched off, where a DPP read of a disabled lane returns 0)
+        unsigned z01[2], z23[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            z01[u] = (quad_pairs_u32(lo01, u) & odd_mask) | (quad_pairs_u32(hi01, u) & ~odd_mask);
+            z23[u] = (quad_pairs_u32(lo23, u) & odd_mask) | (quad_pairs_u32(hi23, u) & ~odd_mask);
+        }
+        if (rows > 0 && __builtin_amdgcn_ballot_w64(fast) != 0ull) {   // (wave-uniform: staged, and somebody reads it)
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
                 const unsigned pk = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane4 + 4 * tp, (int)pack);
                 const bool counts = ((pk >> (20 + jc)) & 1u) != 0u;
                 const int addr = counts ? (int)(pk & 0xfffffu) + dj : kZeroOff;
-                // rows 0, 2 of A: the hi terms, rows 1, 3: the lo terms, all from the quad's lane tp
-                // (bitwise, not ?: -- the compiler turns a select of two DPP moves into a branch and runs each
-                // move with half of the lanes switched off, where a DPP read of a disabled lane returns 0)
-                const unsigned a0 = (quad_bcast_u32(lo01, tp) & odd_mask) | (quad_bcast_u32(hi01, tp) & ~odd_mask);
-                const unsigned a1 = (quad_bcast_u32(lo23, tp) & odd_mask) | (quad_bcast_u32(hi23, tp) & ~odd_mask);
+                const unsigned a0 = quad_evenodd_u32(z01[tp >> 1], tp & 1), a1 = quad_evenodd_u32(z23[tp >> 1], tp & 1);
                 const fwd_i16x4 av = __builtin_bit_cast(fwd_i16x4, uint2{a0, a1});
                 typedef __attribute__((address_space(3))) fwd_i16x4 lds_vec;
 #pragma unroll

@@ -353,6 +353,8 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      0 default (on), 1 off (stand-alone bin_scan_a_kernel / bin_scan_kernel)
  *  16  matrix-core accumulate of bf16 box attention: 0 default (binned_accumulate_tr_kernel: rows read
  *      with the transposing LDS read), 1 the round-1/2 kernel (binned_accumulate_mfma_kernel)
+ *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
+ *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  */
 int boxattn_set_option(int key, int value);
 

@@ -28,7 +28,7 @@ bash tools/gpu_pmc_multi.sh r03sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_
   "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" > $R/pmc_sq.txt 2>&1
 rm -rf gpurun_out/pmc_r03sq_1 gpurun_out/pmc_r03sq_2 gpurun_out/pmc_r03sq_3
 # this round's switches, one at a time against the default (boxattn_set_option key=value)
-for o in "" "11=1" "15=1" "16=1" "14=2" "11=1 --opt 16=1 --opt 15=1"; do
+for o in "" "17=1" "11=1" "15=1" "16=1" "14=2" "17=1 --opt 11=1 --opt 16=1 --opt 15=1"; do
   for inp in model test; do
     echo -n "opt ${o:-default} inputs $inp : " >> $R/ab_switches.log
     timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --inputs $inp ${o:+--opt $o} 2>/dev/null | tail -1 | python -c "

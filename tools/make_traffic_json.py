@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-SLOT = {"fwd2_kernel": "fwd", "fwd_fast_kernel": "fwd", "pointgrad2_kernel": "bwd_points",
+SLOT = {"fwd2_kernel": "fwd", "fwd_dense_kernel": "fwd", "fwd_fast_kernel": "fwd", "pointgrad2_kernel": "bwd_points",
         "bwd_fast_kernel": "bwd_points", "binned_accumulate_kernel": "bwd_accumulate",
         "binned_accumulate_mfma_kernel": "bwd_accumulate", "binned_accumulate_tr_kernel": "bwd_accumulate",
         "pointgrad_dense_kernel": "bwd_points"}
