@@ -62,7 +62,8 @@ constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
 // PT = 4 (P % 4 == 0, 16-byte aligned tensors): a thread takes four consecutive points of one
 // (query, level) with two 16-byte loads and one level lookup (count pass 13.5 -> 11.7 us);
 // PT = 1: any P.
-template <int BW, int BH, bool FILL, bool WIDE, bool INTERLEAVE, int PT>
+// REC12 (with FILL and WIDE): 12-byte records, see touched_blocks12() (boxattn_binplan.h).
+template <int BW, int BH, bool FILL, bool WIDE, bool INTERLEAVE, int PT, bool REC12 = false>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc,
                                                   const float *__restrict__ w_sp, BinPlan plan,
                                                   int H, int Lq, int P, int q_per_wg, int n_wg,
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
 #pragma unroll
             for (int k = 0; k < PT; ++k) {
                 int blk[4];
-                touched_blocks(xy[u][k].x, xy[u][k].y, lv, blk);
+                unsigned rel[4] = {0u, 0u, 0u, 0u}, qf = 0u;
+                if constexpr (FILL && WIDE && REC12) touched_blocks12(xy[u][k].x, xy[u][k].y, lv, blk, rel, qf);
+                else touched_blocks(xy[u][k].x, xy[u][k].y, lv, blk);
                 // predicated, not redirected to a dump slot: same-address LDS atomics serialise
                 // per lane, a shared dump slot made this kernel 1.6x slower
 #pragma unroll
@@ -180,7 +183,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
                         if (BOXATTN_TUNE_FILL_ABLATE == 2 && slot != -12345) continue;
                         if constexpr (FILL) {
                             const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | (lp0[u] + k);
-                            if constexpr (WIDE)
+                            if constexpr (WIDE && REC12)
+                                reinterpret_cast<BinRec12 *>(rec)[slot] =
+                                    BinRec12{(int)((unsigned)id | ((rel[j] & 15u) << 24) | ((rel[j] >> 4) << 28)),
+                                             __float_as_int(wv[u][k]), (int)qf};
+                            else if constexpr (WIDE)
                                 reinterpret_cast<int4 *>(rec)[slot] =
                                     make_int4(id, __float_as_int(xy[u][k].x),
                                               __float_as_int(xy[u][k].y), __float_as_int(wv[u][k]));

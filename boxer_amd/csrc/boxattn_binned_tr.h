@@ -46,7 +46,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned short *base, unsig
     return __builtin_bit_cast(uint2, v);
 }
 
-template <typename ST, int C>
+// REC12: 12-byte records (boxattn_binplan.h touched_blocks12: footprint corner relative to the block, 16-bit
+// fractions) instead of the 16-byte {id, x, y, weight}: 25 % less of the stream the fill pass writes and this
+// kernel reads (the fill pass is bound by exactly those bytes), and no locate() per record here.
+template <typename ST, int C, bool REC12>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BOXATTN_TUNE_TR_WPE : 1))) void binned_accumulate_tr_kernel(
     const ST *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
             if (k == bg.level) { lvH = plan.lv[k].H; lvW = plan.lv[k].W; lv_start = plan.lv[k].start; }
         const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
         const float Hf = (float)lvH, Wf = (float)lvW;
+        // (a slice's record region is sized for 16-byte records either way)
         const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
+        const BinRec12 *rec12 = reinterpret_cast<const BinRec12 *>(rec);
         tr_f32x16 acc[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -126,10 +131,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
         // dense product any row that happened to be fetched there could poison the block).
         constexpr unsigned kNoRow = 0x80000000u;
         auto fetch_rec = [&](int rr) -> int4 {
-            return rr + lane < item.z ? rec[rr + lane] : make_int4(-1, 0, 0, 0);
+            if (rr + lane >= item.z) return make_int4(-1, 0, 0, 0);
+            if constexpr (REC12) {
+                const BinRec12 r3 = rec12[rr + lane];
+                return make_int4(r3.w0, r3.w1, r3.w2, 0);
+            } else {
+                return rec[rr + lane];
+            }
         };
         auto fetch_rows = [&](const int4 &r, u32x4 (&rows)[NPASS]) {
-            const unsigned off = r.x < 0 ? kNoRow : __umul24((unsigned)r.x >> plan.lp_bits, q_stride) + slice_off;
+            const unsigned id = REC12 ? (unsigned)r.x & 0xffffffu : (unsigned)r.x;
+            const unsigned off = r.x < 0 ? kNoRow : __umul24(id >> plan.lp_bits, q_stride) + slice_off;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const unsigned oj = (unsigned)__shfl((int)off, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
@@ -155,22 +167,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
                 rec_n3 = fetch_rec(rr + 3 * R);
             }
             // ---- lane = record: its <= 4 weights go to A^T[pixel][lane] as hi + lo bf16
-            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
-            float h_im, w_im;
-            {
+            float lh, lw, a;
+            int py, px;                             // footprint corner relative to the block; idle lanes: outside
+            if constexpr (REC12) {
+                a = __int_as_float(rec_c.y);
+                lw = (float)((unsigned)rec_c.z & 0xffffu) * (1.f / 65536.f);
+                lh = (float)((unsigned)rec_c.z >> 16) * (1.f / 65536.f);
+                px = (int)(((unsigned)rec_c.x >> 24) & 15u) - 1;
+                py = rec_c.x >= 0 ? (int)(((unsigned)rec_c.x >> 28) & 7u) - 1 : -2;
+            } else {
+                const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z);
+                a = __int_as_float(rec_c.w);
+                float h_im, w_im;
+                {
 #pragma clang fp contract(off)                   // two roundings, as in locate()
-                h_im = y * Hf - 0.5f;
-                w_im = x * Wf - 0.5f;
+                    h_im = y * Hf - 0.5f;
+                    w_im = x * Wf - 0.5f;
+                }
+                const float yf = floorf(h_im), xf = floorf(w_im);
+                lh = h_im - yf; lw = w_im - xf;
+                py = rec_c.x >= 0 ? (int)yf - oy : -2;
+                px = (int)xf - ox;
             }
-            const float yf = floorf(h_im), xf = floorf(w_im);
-            const float lh = h_im - yf, lw = w_im - xf, hh = 1.f - lh, hw = 1.f - lw;
+            const float hh = 1.f - lh, hw = 1.f - lw;
             const float ha = hh * a, la = lh * a;
             const float w0 = ha * hw, w1 = ha * lw, w2 = la * hw, w3 = la * lw;
             const unsigned hi01 = pack_bf16x2(w0, w1), hi23 = pack_bf16x2(w2, w3);
             const unsigned lo01 = pack_bf16x2(w0 - __uint_as_float(hi01 << 16), w1 - __uint_as_float(hi01 & 0xffff0000u));
             const unsigned lo23 = pack_bf16x2(w2 - __uint_as_float(hi23 << 16), w3 - __uint_as_float(hi23 & 0xffff0000u));
             // byte offsets of the corners' rows / columns inside A^T, kBig when outside the block (idle lanes: all)
-            const int py = rec_c.x >= 0 ? (int)yf - oy : -2, px = (int)xf - ox;
             const int r0 = (unsigned)py < (unsigned)bh ? __mul24(py, BW * ASB) : kBig;
             const int r1 = (unsigned)(py + 1) < (unsigned)bh ? __mul24(py, BW * ASB) + BW * ASB : kBig;
             const int c0 = (unsigned)px < (unsigned)bw ? __mul24(px, ASB) + 2 * lane : kBig;

@@ -43,7 +43,8 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptDenseFill = 14,    // bin records counted / written by the window-staged kernels: 0 default (off), 1 off, 2 on
        kOptAccTr = 16,        // bf16 accumulate: 0 default (binned_accumulate_tr_kernel), 1 binned_accumulate_mfma_kernel
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (BOXATTN_DENSE_FWD_DEFAULT), 1 off, 2 on
-       kNumOpts = 18 };
+       kOptRec12 = 18,        // bf16 box attention: 12-byte bin records: 0 default (off), 1 off, 2 on
+       kNumOpts = 19 };
 #ifndef BOXATTN_DENSE_FWD_DEFAULT
 #define BOXATTN_DENSE_FWD_DEFAULT 2      // 2: on where eligible, 0: off
 #endif
@@ -717,6 +718,18 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
             return false;
         p.lv[l].mw = wl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)wl + 1) : 0u;
         p.lv[l].mh = hl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)hl + 1) : 0u;
+        // blk_lo_magic(): first coordinate of a block by multiply-high, checked against the division
+        const auto lo_magic = [](long long size, int nb) -> unsigned {
+            const unsigned m = (unsigned)((1ull << 32) / (unsigned long long)nb + 1);
+            if (nb == 1) return 0u;          // (one block: its origin is 0, which a magic of 0 delivers)
+            for (int c = 0; c <= nb; ++c) {
+                const unsigned long long n = (unsigned long long)c * size + nb - 1;
+                if (n >= (1ull << 23) || (unsigned)((n * m) >> 32) != (unsigned)(n / nb)) return 0u;     // (n: a 24-bit multiply + nb)
+            }
+            return m;
+        };
+        p.lv[l].mnx = lo_magic(wl, p.lv[l].nbx);
+        p.lv[l].mny = lo_magic(hl, p.lv[l].nby);
         p.lv[l].blk0 = (int)blk0;
         blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
     }
@@ -792,7 +805,7 @@ inline WsLayout ws_layout(const Dims &d, const BinPlan &p, bool wide)
 // read the sampling locations, so the training forward can run them ahead of the backward.
 template <bool WIDE, bool INTERLEAVE>
 inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                             const WsLayout &w, char *ws, hipStream_t st, int stages);
+                             const WsLayout &w, char *ws, hipStream_t st, int stages, bool rec12);
 // wide: 16-byte records; interleave: queries interleaved over the bin workgroups (VALU accumulate)
 // stages: kBinCount | kBinScan | kBinFill (all three in one call, or -- the training forward, which
 // lets the scans ride in the forward kernel's launch -- one at a time)
@@ -800,12 +813,36 @@ enum { kBinCount = 1, kBinScan = 2, kBinFill = 4, kBinAll = 7,
        kBinTickets = 8 };    // with kBinCount: clear the tickets of the scans that will ride in the forward kernel
 inline void launch_binning(bool wide, bool interleave, const float *loc, const float *w_sp,
                            const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws,
-                           hipStream_t st, int stages = kBinAll)
+                           hipStream_t st, int stages = kBinAll, bool rec12 = false)
 {
-    if (wide && interleave) launch_binning_t<true, true>(loc, w_sp, d, plan, w, ws, st, stages);
-    else if (wide) launch_binning_t<true, false>(loc, w_sp, d, plan, w, ws, st, stages);
-    else if (interleave) launch_binning_t<false, true>(loc, w_sp, d, plan, w, ws, st, stages);
-    else launch_binning_t<false, false>(loc, w_sp, d, plan, w, ws, st, stages);
+    // rec12 (wide, not interleaved): the fill pass writes 12-byte records (touched_blocks12)
+    if (wide && interleave) launch_binning_t<true, true>(loc, w_sp, d, plan, w, ws, st, stages, false);
+    else if (wide) launch_binning_t<true, false>(loc, w_sp, d, plan, w, ws, st, stages, rec12);
+    else if (interleave) launch_binning_t<false, true>(loc, w_sp, d, plan, w, ws, st, stages, false);
+    else launch_binning_t<false, false>(loc, w_sp, d, plan, w, ws, st, stages, false);
+}
+// may the matrix-core accumulate of this call be binned_accumulate_tr_kernel (what 12-byte records need)?
+template <typename ST, int C> inline bool accumulate_tr_ok(const Dims &d)
+{
+    if constexpr (std::is_same<ST, bf16_t>::value && (C == 16 || C == 32 || C == 64))
+        return (size_t)d.B * d.Lq * d.H * C * sizeof(ST) < kAccTrMaxBytes && d.Lq < (1 << 24) && d.H * C * 2 < (1 << 24);
+    return false;
+}
+// 12-byte bin records (bf16 box attention on the matrix-core accumulate): ids below 2^24 and exact block origins
+template <typename ST, bool INST> inline bool rec12_ok(const Dims &d, const BinPlan &plan)
+{
+    if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
+        // (opt-in: the 16-bit fractions cost the "single terms correctly rounded" guarantee of the 16-byte records --
+        // an ABSOLUTE 2^-17 on a bilinear fraction is a large relative error on a tiny weight -- for 2.6 us of 142)
+        if (opt(kOptRec12) != 2 || opt(kOptAccTr) == 1 || g_variant == 11) return false;
+        const bool tr = d.C == 16 ? accumulate_tr_ok<ST, 16>(d) : d.C == 32 ? accumulate_tr_ok<ST, 32>(d)
+                                  : d.C == 64 ? accumulate_tr_ok<ST, 64>(d) : false;
+        if (!tr || ((long long)d.Lq << plan.lp_bits) > (1ll << 24)) return false;
+        for (int l = 0; l < plan.L; ++l)
+            if ((plan.lv[l].nbx > 1 && !plan.lv[l].mnx) || (plan.lv[l].nby > 1 && !plan.lv[l].mny)) return false;
+        return true;
+    }
+    return false;
 }
 // Can the two scan kernels of this plan run as bin_scan_tail_body workgroups?
 inline bool scan_tail_ok(const BinPlan &plan, const WsLayout &w)
@@ -824,7 +861,7 @@ inline ScanTail scan_tail(const BinPlan &plan, const WsLayout &w, char *ws)
 }
 template <bool WIDE, bool INTERLEAVE>
 inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                             const WsLayout &w, char *ws, hipStream_t st, int stages)
+                             const WsLayout &w, char *ws, hipStream_t st, int stages, bool rec12)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
@@ -879,7 +916,20 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
         hipLaunchKernelGGL(bin_scan_kernel, dim3(ns), dim3(kScanThreads), 0, st, subtot, offsets,
                            items, combos, n_items, plan, part, fuse_a ? w.n_wg : 0);
     }
-    if (stages & kBinFill) BOXATTN_BIN(true);
+    if ((stages & kBinFill) && rec12) {
+        if constexpr (WIDE && !INTERLEAVE) {          // 12-byte records (bf16 box attention)
+            if (pt4)
+                hipLaunchKernelGGL((bin_kernel<BW, BH, true, true, false, 4, true>), bgrid, dim3(kBinThreads), bsh, st,
+                                   loc, w_sp, plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets,
+                                   records, tickets);
+            else
+                hipLaunchKernelGGL((bin_kernel<BW, BH, true, true, false, 1, true>), bgrid, dim3(kBinThreads), bsh, st,
+                                   loc, w_sp, plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, part, subtot, offsets,
+                                   records, tickets);
+        }
+    } else if (stages & kBinFill) {
+        BOXATTN_BIN(true);
+    }
 #undef BOXATTN_BIN
 }
 
@@ -1098,13 +1148,13 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
 template <typename ST, int C>
 void launch_accumulate_mfma(const ST *grad_out, const Dims &d, const BinPlan &plan, int wg_per_slice, int ns8,
                             const int4 *items, const int *n_items, const int *records, ST *grad_value,
-                            float *partials, hipStream_t st)
+                            float *partials, hipStream_t st, bool rec12 = false)
 {
     if constexpr (std::is_same<ST, bf16_t>::value && (C == 16 || C == 32 || C == 64)) {
         const size_t go_bytes = (size_t)d.B * d.Lq * d.H * C * sizeof(ST);
-        if (opt(kOptAccTr) != 1 && go_bytes < kAccTrMaxBytes && d.Lq < (1 << 24) && d.H * C * 2 < (1 << 24)) {
+        if ((rec12 || opt(kOptAccTr) != 1) && accumulate_tr_ok<ST, C>(d)) {      // (12-byte records: this kernel only)
             launch_accumulate_tr(C, grad_out, go_bytes, plan, d.S, d.H, d.Lq, items, n_items, records, grad_value,
-                                 partials, wg_per_slice, ns8, st);
+                                 partials, wg_per_slice, ns8, rec12, st);
             return;
         }
     }
@@ -1118,8 +1168,9 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const WsLayout &w, char *ws, ST *grad_value,
                float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready, hipStream_t st,
-               const GridSrc *gs = nullptr, const DensePlan *dp = nullptr, int dense_fill = 0)
+               const GridSrc *gs = nullptr, const DensePlan *dp = nullptr, int dense_fill = 0, bool rec12 = false)
 {
+    // rec12: 12-byte bin records (this call's fill pass or the training forward's whose plan this is)
     // dense_fill: 0 no; 1 the window-staged kernels bin (count + scan here, records by the point-gradient
     // kernel); 2 the same, counted and scanned already (by the training forward)
     const int ns = d.B * d.H;
@@ -1155,7 +1206,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // in-order stream (also valid under stream capture).
     SideStream side(st, side_stream_worth<ST>(d));
     const bool use_mfma = mfma_accumulate<ST, INST>(d), wide = wide_records<ST, INST>(d);
-    if (!plan_ready) launch_binning(wide, !use_mfma, loc, w_sp, d, plan, w, ws, st);
+    if (!plan_ready) launch_binning(wide, !use_mfma, loc, w_sp, d, plan, w, ws, st, kBinAll, rec12);
     // On one stream the point gradients go LAST and carry the combine step's workers as extra
     // workgroups (CombineTail): one launch less, 5-7 us of every step.  With the helper stream
     // (variant 6) they run next to the binning / accumulate kernels and the combine step keeps
@@ -1197,7 +1248,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         if constexpr (kMfmaBuilt) {
             if (use_mfma) {
                 launch_accumulate_mfma<ST, 4 * G>(grad_out, d, plan, wg_per_slice, ns8, items, n_items, records,
-                                                  grad_value, partials, st);
+                                                  grad_value, partials, st, rec12);
                 done = true;
             }
         }
@@ -1369,7 +1420,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         return kNotEligible;                 // the caller falls back to the grid tensor's own kernels
     if constexpr (kBf16 && !INST) {      // encoder case: no global binning (boxattn_qgrid.h)
         QgPlan qp;
-        if (binned && plan_kind != 1 && aligned(grad_out, 16) && aligned(loc, 16) &&
+        if (binned && plan_kind != 1 && plan_kind != 4 && aligned(grad_out, 16) && aligned(loc, 16) &&
             make_qg_plan(d, shapes_host, lsi_host, qp)) {
             const QgLayout qw = qg_layout(d, qp);
             if (workspace_bytes >= qw.total) {
@@ -1384,7 +1435,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         }
         if (plan_kind == 2) plan_kind = 0;     // boxes in the workspace, but the binned path runs
     }
-    const bool plan_ready = plan_kind == 1;      // (kind 3 -- counted by the window-staged kernels -- see below)
+    const bool plan_ready = plan_kind == 1 || plan_kind == 4;   // 4: with 12-byte records (kind 3 -- counted by the window-staged kernels -- see below)
     WsLayout w{};
     if (binned) {
         w = ws_layout(d, plan, wide_workspace(kBf16, d));
@@ -1417,15 +1468,17 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     // the window-staged kernels as the binning passes: whenever they compute the point gradients and the
     // matrix-core accumulate reads wide records (a forward-built classic plan, kind 1, is used as it is)
     int dense_fill = 0;
-    if (!gs && plan_kind != 1 && dense_fill_ok(dp, plan) && mfma_accumulate<ST, INST>(d) &&
+    if (!gs && !plan_ready && dense_fill_ok(dp, plan) && mfma_accumulate<ST, INST>(d) &&
         dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp))
         dense_fill = plan_kind == 3 ? 2 : 1;
+    // 12-byte records: as the plan's forward wrote them, or this call's own fill pass
+    const bool rec12 = plan_kind == 4 || (!plan_ready && !dense_fill && rec12_ok<ST, INST>(d, plan));
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, w, ws, grad_value, grad_loc, grad_sp, grad_lv,   \
-                                      plan_ready, st, gs, dp, dense_fill);                      \
+                                      plan_ready, st, gs, dp, dense_fill, rec12);               \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -1486,6 +1539,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
     }
     SideStream side(st, side_stream_worth<ST>(d));
     const bool wide = wide_records<ST, INST>(d), inter = !mfma_accumulate<ST, INST>(d);
+    const bool rec12 = wide && !inter && rec12_ok<ST, INST>(d, plan);
     if (!INST && side.stream() == st && scan_tail_ok(plan, w)) {
         // count -> forward kernel + the scans as extra workgroups of its launch -> fill
         launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, st, kBinCount | kBinTickets);
@@ -1494,15 +1548,15 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
                                             shapes_host, lsi_host, &tail, &taken);
         launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, st,
-                       taken ? kBinFill : (kBinScan | kBinFill));
-        if (rc == 0 && plan_built) *plan_built = 1;
+                       taken ? kBinFill : (kBinScan | kBinFill), rec12);
+        if (rc == 0 && plan_built) *plan_built = rec12 ? 4 : 1;
         return rc;
     }
-    launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, side.stream());
+    launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, side.stream(), kBinAll, rec12);
     const int rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
                                         shapes_host, lsi_host);
     side.join();
-    if (rc == 0 && plan_built) *plan_built = 1;
+    if (rc == 0 && plan_built) *plan_built = rec12 ? 4 : 1;
     return rc;
 }
 

@@ -67,16 +67,16 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
 
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
                           int H, int Lq, const int4 *items, const int *n_items, const int *records,
-                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, hipStream_t st)
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, bool rec12, hipStream_t st)
 {
-#define BOXATTN_ACC_TR(C_)                                                                              \
-    case C_:                                                                                            \
-        hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
-                           grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, \
-                           grad_value, partials);                                                       \
-        break;
+#define BOXATTN_ACC_TR(C_, R_)                                                                          \
+    hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_, R_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
+                       grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records,     \
+                       grad_value, partials)
     switch (C) {
-        BOXATTN_ACC_TR(16) BOXATTN_ACC_TR(32) BOXATTN_ACC_TR(64)
+    case 16: if (rec12) BOXATTN_ACC_TR(16, true); else BOXATTN_ACC_TR(16, false); break;
+    case 32: if (rec12) BOXATTN_ACC_TR(32, true); else BOXATTN_ACC_TR(32, false); break;
+    case 64: if (rec12) BOXATTN_ACC_TR(64, true); else BOXATTN_ACC_TR(64, false); break;
     }
 #undef BOXATTN_ACC_TR
 }

@@ -117,6 +117,6 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
 constexpr size_t kAccTrMaxBytes = (size_t)1 << 31;
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
                           int H, int Lq, const int4 *items, const int *n_items, const int *records,
-                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, hipStream_t st);
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, bool rec12, hipStream_t st);
 
 }  // namespace boxattn

@@ -97,7 +97,7 @@ class BackwardPlan:
 
     def __init__(self, ws, key, kind=1):
         # kind: 1 = binning plan, 2 = query-grid tile boxes, 3 = counted bins whose records the
-        # backward writes (what *_fwd_train_* reported)
+        # backward writes, 4 = binning plan with 12-byte records (what *_fwd_train_* reported)
         self.ws, self.key, self.kind = ws, key, kind
 
 

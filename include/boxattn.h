@@ -141,7 +141,8 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  * the binning plan, 2: it holds the query-grid tile boxes (bf16 box attention in the encoder
  * case, Lq == S: no global binning at all), 3: it holds the counted and
  * scanned bins whose records the backward's point-gradient kernel writes itself (bf16 box attention
- * in the encoder case, window-staged kernels).  A plan the backward cannot use
+ * in the encoder case, window-staged kernels), 4: like 1 with 12-byte bin records
+ * (bf16 box attention).  A plan the backward cannot use
  * (operands the fast paths reject) is ignored and the call falls back.
  * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`; with
  * boxattn_set_variant(6) the point-gradient kernel runs on a library-owned low-priority helper
@@ -353,6 +354,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      0 default (on), 1 off (stand-alone bin_scan_a_kernel / bin_scan_kernel)
  *  16  matrix-core accumulate of bf16 box attention: 0 default (binned_accumulate_tr_kernel: rows read
  *      with the transposing LDS read), 1 the round-1/2 kernel (binned_accumulate_mfma_kernel)
+ *  18  12-byte bin records for bf16 box attention (footprint corner relative to the block + 16-bit fractions
+ *      instead of float32 coordinates): 0 / 1 off (default), 2 on -- 2 % faster, but a weight is then exact to
+ *      2^-17 ABSOLUTE instead of relative.  Set before *_fwd_train_* / the backward.
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  */

@@ -237,6 +237,38 @@ def test_box_backward_algorithms(cfg, dtype, variant):
     close(ga, want[2], torch.float32, "grad_attn")
 
 
+OPT_REC12 = 18          # boxattn_set_option: 2 = 12-byte bin records for bf16 box attention (opt-in), 0 / 1 = 16-byte records
+
+
+@pytest.mark.parametrize("with_plan", [False, True], ids=["own_binning", "forward_plan"])
+@pytest.mark.parametrize("cfg", FAST_CFGS + [SEEDED[6], SEEDED[7]], ids=[str(i) for i in range(len(FAST_CFGS) + 2)])
+def test_both_bin_record_formats(cfg, with_plan):
+    """bf16 grad_value through 12-byte records (footprint corner relative to the destination block, 16-bit
+    fractions) and through 16-byte records (float32 coordinates): both against the oracle and against each
+    other to 2^-16 of a weight; with the backward's own binning and with a training forward's plan."""
+    from boxer_amd import _lib, ops
+    g = _seeded(*cfg, seed=29, lo=-0.2, hi=1.2)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])
+    value, loc, attn = dev(g["value"], torch.bfloat16), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
+    shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], torch.bfloat16)
+    res = {}
+    for mode in (2, 1):
+        old = _lib.load().boxattn_set_option(OPT_REC12, mode)
+        try:
+            if with_plan:
+                _, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
+                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)[0]
+            else:
+                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64)[0]
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().boxattn_set_option(OPT_REC12, old)
+        res[mode] = gv
+        close(gv, want[0], torch.bfloat16, "grad_value (records %d)" % mode)
+    a, b = res[2].float(), res[1].float()
+    assert (a - b).abs().max().item() <= 2.0 ** -7 * max(1.0, b.abs().max().item())
+
+
 OPT_ACC_TR = 16         # boxattn_set_option: 0 binned_accumulate_tr_kernel (default), 1 binned_accumulate_mfma_kernel
 
 
