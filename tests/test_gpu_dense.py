@@ -111,6 +111,26 @@ def test_dense_kernels_match_oracle(lv, family, dense_switch, binning, forward_k
         assert worst <= tol, "%s/%s %s: worst %.3e > %.0e" % (lv, family, name, worst, tol)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_dense_kernels_random_shapes(seed, dense_switch):
+    """A seeded sweep over what the hand-picked cases may miss: 1-4 levels of random (also degenerate) sizes
+    with random down-scaling between them, 1-3 images, 1-8 heads, a random input family -- forward and
+    backward of the window-staged kernels against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.integers(1, 5))
+    h, w = int(rng.integers(3, 45)), int(rng.integers(3, 45))
+    levels = []
+    for _ in range(L):
+        levels.append((h, w))
+        h, w = max(1, int(np.ceil(h / rng.uniform(1.5, 2.6)))), max(1, int(np.ceil(w / rng.uniform(1.5, 2.6))))
+    family = ["model", "test", "mixed", "border"][int(rng.integers(0, 4))]
+    dense_switch(True)
+    inp = make_case(levels, family, H=int(rng.integers(1, 9)), B=int(rng.integers(1, 4)), seed=seed)
+    out, grads = run(inp, with_plan=bool(rng.integers(0, 2)))
+    for name, worst, tol in bench.parity_report(inp, out, grads):
+        assert worst <= tol, "levels %s %s %s: worst %.3e > %.0e" % (levels, family, name, worst, tol)
+
+
 @pytest.mark.parametrize("H", [1, 4, 6, 8])
 def test_dense_kernels_head_counts(H, dense_switch, binning, forward_kernel):
     dense_switch(True)
