@@ -409,17 +409,22 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                 if (wide) {
                     const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
                                                     : ceil_div_sz(n_qh, 4);
+                    const bool wtail = scan_tail && scan_tail->n_wg > 0;
+                    const ScanTail wsct = wtail ? *scan_tail : ScanTail{};
+                    const int wlead = wtail ? wsct.plan.n_slices * kScanSub : 0;        // in FRONT of the grid
+                    ix.lead = (unsigned)wlead;
 #define BOXATTN_FWD_WIDE(GG, VV)                                                              \
-    hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(wblocks), dim3(256), 0, st,   \
+    hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(wblocks + wlead), dim3(256), 0, st, \
                        value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out,    \
-                       mask, with_grid(ix, wblocks, 1, 1), (unsigned)vbytes);
+                       mask, with_grid(ix, wblocks, 1, 1), (unsigned)vbytes, wsct);
                     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD_WIDE);
 #undef BOXATTN_FWD_WIDE
+                    if (wtail && scan_tail_taken) *scan_tail_taken = true;
                     return finish();
                 }
             }
             if (gen2) {
-                const bool tail = !INST && scan_tail && scan_tail->n_wg > 0 && fsplit == 1;
+                const bool tail = scan_tail && scan_tail->n_wg > 0 && fsplit == 1;
                 const ScanTail sct = tail ? *scan_tail : ScanTail{};
                 const int tail_blocks = tail ? sct.plan.n_slices * kScanSub : 0;        // in FRONT of the grid (kScanSub = 8 each)
                 ix.lead = (unsigned)tail_blocks;
@@ -1540,7 +1545,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
     SideStream side(st, side_stream_worth<ST>(d));
     const bool wide = wide_records<ST, INST>(d), inter = !mfma_accumulate<ST, INST>(d);
     const bool rec12 = wide && !inter && rec12_ok<ST, INST>(d, plan);
-    if (!INST && side.stream() == st && scan_tail_ok(plan, w)) {
+    if (side.stream() == st && scan_tail_ok(plan, w)) {
         // count -> forward kernel + the scans as extra workgroups of its launch -> fill
         launch_binning(wide, inter, loc, w_sp, d, plan, w, (char *)workspace, st, kBinCount | kBinTickets);
         const ScanTail tail = scan_tail(plan, w, (char *)workspace);

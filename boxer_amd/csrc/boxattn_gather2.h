@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
 {
     static_assert(!(GRID && INST), "boxes -> grid is built for box attention");
     constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
-    if constexpr (!INST && !GRID) {
+    if constexpr (!GRID) {
         // the training forward: the backward's two scan kernels as one extra workgroup per slice
         // (bin_scan_tail_body): they only need the count pass, which ran before this launch
         // (they take the FIRST workgroup ids -- dispatched first, done long before the forward's last
@@ -568,19 +568,27 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
-    int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes)
+    int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
+    ScanTail sct = ScanTail{})
 {
     constexpr int C = VEC * G, NG = kWave / G;
     typedef Row<ST, VEC> RowT;
     constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;
     constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);
+    // the training forward: the backward's block scans as ix.lead extra workgroups in front (fwd2_kernel)
+    if (sct.n_wg > 0 && blockIdx.x < ix.lead) {
+        if ((int)blockIdx.x < sct.plan.n_slices * kScanSub)
+            bin_scan_tail_body<256>(sct, (int)blockIdx.x / kScanSub, (int)blockIdx.x % kScanSub);
+        return;
+    }
+    const unsigned blk = blockIdx.x - ix.lead;
     __shared__ LevelTable lv;
     load_levels(lv, shapes, lsi, L);
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    unsigned qh = blockIdx.x * kGatherWaves + wv;            // one pair per wave
+    unsigned qh = blk * kGatherWaves + wv;                   // one pair per wave
     if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
-        qh = ((blockIdx.x / 8) * kGatherWaves + wv) * (unsigned)H + blockIdx.x % 8;
+        qh = ((blk / 8) * kGatherWaves + wv) * (unsigned)H + blk % 8;
     if (qh >= ix.n_qh) return;                                          // wave-uniform
     const int slot = lane % G, grp = lane / G;
     unsigned bq, hu, b, qu;
