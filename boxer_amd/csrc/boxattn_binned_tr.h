@@ -293,4 +293,163 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     }
 }
 
+// float32 storage, 32 channels per head: the same product on v_mfma_f32_32x32x2_f32 -- float32 operands, float32
+// products and accumulation: no splitting, no rounding beyond what any float32 summation order has (the VALU
+// list walk of binned_accumulate_kernel is float32 too, in another order).  An operand of that instruction is ONE
+// element per lane (row / column l & 31, k = l >> 5 of the 2 records of a step), so nothing has to be transposed:
+// the gathered rows are staged as they arrive, G[record][channel] (8 KB), and read back one dword per lane (32
+// consecutive dwords per half-wave: conflict-free); the weights are scattered as float32 into A^T[record][pixel]
+// (lane = record writes inside its own 132-byte row; a 33rd column takes the corners outside the block).
+// 32 MFMAs of 64 cycles per round: the kernel is bound by the matrix pipe (61 us at C2 for 73 k rounds) instead of
+// the VALU kernel's list walk (103 us).  Wide records {id, x, y, weight} as the bf16 kernel.
+template <int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void binned_accumulate_f32_kernel(
+    const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
+    const int4 *__restrict__ items, const int *__restrict__ n_items,
+    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials)
+{
+    static_assert(C == 32, "channels per head");
+    constexpr int BW = 8, PB = 32, R = 64;
+    constexpr int ROWB = C * 4;                    // bytes of one upstream-gradient row
+    constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each (8)
+    constexpr int RPP = 64 / LPR;                  // rows fetched per pass (8)
+    constexpr int NPASS = R / RPP;                 // 8
+    constexpr int AP = PB + 1;                     // floats per A^T row: 32 pixels + the dump column
+    constexpr int kBig = 1 << 20;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float gs[R * C];
+    __shared__ __attribute__((aligned(16))) float at[R * AP];
+
+    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = bid % 8, kq = bid / 8;
+    const int per_xcd = (n_slices + 7) / 8;
+    const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
+    const int worker = kq / per_xcd;
+    if (s >= n_slices || worker >= workers) return;
+    const int b = s / H, h = s % H;
+    const int lane = threadIdx.x;
+    const int col = lane & 31, kb = lane >> 5;     // operand row / column, record of the K = 2 step
+    const int n_it = n_items[2 * s];
+
+    for (int i = lane; i < R * AP; i += 64) at[i] = 0.f;
+    wave_lds_sync();
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out), 0, grad_out_bytes, 0x00020000);
+    const unsigned slice_off = (unsigned)((b * Lq) * H + h) * (unsigned)ROWB;
+    const unsigned q_stride = (unsigned)(H * ROWB);
+    const int piece = lane % LPR, jrow = lane / LPR;
+
+    const int4 *my_items = items + (size_t)s * plan.item_cap;
+    int4 item_n = my_items[min(worker, plan.item_cap - 1)];
+    for (int it = worker; it < n_it; it += workers) {
+        const int4 item = item_n;
+        item_n = my_items[min(it + workers, plan.item_cap - 1)];
+        const BlockGeo bg = unpack_block_geo((unsigned)item.x);
+        int lvH = plan.lv[0].H, lvW = plan.lv[0].W, lv_start = plan.lv[0].start;
+#pragma unroll
+        for (int k = 1; k < kMaxBinLevels; ++k)
+            if (k == bg.level) { lvH = plan.lv[k].H; lvW = plan.lv[k].W; lv_start = plan.lv[k].start; }
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
+        const float Hf = (float)lvH, Wf = (float)lvW;
+        const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
+        tr_f32x16 acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+
+        // records two rounds ahead, rows one (the kernel waits for the matrix pipe, not for memory); idle lanes of
+        // the last round fetch from outside the buffer: zeros
+        constexpr unsigned kNoRow = 0x80000000u;
+        auto fetch_rec = [&](int rr) -> int4 {
+            return rr + lane < item.z ? rec[rr + lane] : make_int4(-1, 0, 0, 0);
+        };
+        u32x4 rows[NPASS];
+        auto fetch_rows = [&](const int4 &r) {
+            const unsigned off = r.x < 0 ? kNoRow : __umul24((unsigned)r.x >> plan.lp_bits, q_stride) + slice_off;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned oj = (unsigned)__shfl((int)off, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
+                rows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, oj, 0, 0);
+            }
+        };
+        auto stage_rows = [&]() {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(gs) + (ps * 64 + lane) * 16) = rows[ps];
+        };
+        int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R);
+        fetch_rows(rec_c);
+        stage_rows();
+        for (int rr = item.y; rr < item.z; rr += R) {
+            const bool more = rr + R < item.z;     // wave-uniform
+            int4 rec_n2 = make_int4(-1, 0, 0, 0);
+            if (more) {
+                fetch_rows(rec_n);
+                rec_n2 = fetch_rec(rr + 2 * R);
+            }
+            // ---- lane = record: its <= 4 weights go to A^T[lane][pixel]
+            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
+            float h_im, w_im;
+            {
+#pragma clang fp contract(off)                   // two roundings, as in locate()
+                h_im = y * Hf - 0.5f;
+                w_im = x * Wf - 0.5f;
+            }
+            const float yf = floorf(h_im), xf = floorf(w_im);
+            const float lh = h_im - yf, lw = w_im - xf, hh = 1.f - lh, hw = 1.f - lw;
+            // (the reference's products: (hh hw) a etc. -- kept in that order)
+            const float wk[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+            const int py = rec_c.x >= 0 ? (int)yf - oy : -2, px = (int)xf - ox;
+            const int r0 = (unsigned)py < (unsigned)bh ? py * BW : kBig;
+            const int r1 = (unsigned)(py + 1) < (unsigned)bh ? (py + 1) * BW : kBig;
+            const int c0 = (unsigned)px < (unsigned)bw ? px : kBig;
+            const int c1 = (unsigned)(px + 1) < (unsigned)bw ? px + 1 : kBig;
+            float *my = at + lane * AP;
+            const int slot[4] = {min(r0 + c0, PB), min(r0 + c1, PB), min(r1 + c0, PB), min(r1 + c1, PB)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) my[slot[k]] = wk[k];
+            wave_lds_sync();
+            // ---- the product: 32 K-steps of 2 records
+            // (two accumulator chains: a dependent 32x32 MFMA waits for its predecessor's 64 cycles + latency)
+#pragma unroll
+            for (int t = 0; t < R / 2; t += 2) {
+                const float g0 = gs[(2 * t + kb) * C + col], g1 = gs[(2 * t + 2 + kb) * C + col];
+                const float p0 = at[(2 * t + kb) * AP + col], p1 = at[(2 * t + 2 + kb) * AP + col];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, p0, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, p1, acc2, 0, 0, 0);
+            }
+            wave_lds_sync();
+            // ---- clear this round's weights, stage the next round's rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) my[slot[k]] = 0.f;
+            if (more) {
+                stage_rows();
+                rec_c = rec_n; rec_n = rec_n2;
+            }
+            wave_lds_sync();
+        }
+        // ---- store.  Lane = pixel `col`; its registers hold channels 8 g + 4 kb + 0..3.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        if (item.w < 0) {
+            const int py = col / BW, px = col % BW;
+            const bool live = py < bh && px < bw;
+            float *dst = grad_value +
+                         (((size_t)b * S + lv_start + (size_t)(oy + py) * lvW + (ox + px)) * H + h) * C;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                if (live)
+                    *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) =
+                        make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+        } else {
+            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + col) * C;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) =
+                    make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+        }
+    }
+}
+
 }  // namespace boxattn

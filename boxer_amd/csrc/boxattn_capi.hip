@@ -44,7 +44,8 @@ enum { kOptTileShape = 0, kOptTileRows = 1, kOptTileMarginCap = 2, kOptTileStati
        kOptAccTr = 16,        // bf16 accumulate: 0 default (binned_accumulate_tr_kernel), 1 binned_accumulate_mfma_kernel
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (BOXATTN_DENSE_FWD_DEFAULT), 1 off, 2 on
        kOptRec12 = 18,        // bf16 box attention: 12-byte bin records: 0 default (off), 1 off, 2 on
-       kNumOpts = 19 };
+       kOptAccF32 = 19,       // float32 box attention, C = 32: accumulate on v_mfma_f32_32x32x2_f32: 0 / 1 off (default: VALU list walk), 2 on
+       kNumOpts = 20 };
 #ifndef BOXATTN_DENSE_FWD_DEFAULT
 #define BOXATTN_DENSE_FWD_DEFAULT 2      // 2: on where eligible, 0: off
 #endif
@@ -668,11 +669,19 @@ template <typename ST> inline bool side_stream_worth(const Dims &) { return fals
 // 32 channels per head) exists and is parity-green, but measured no gain at BoxeR-R50 shapes --
 // accumulate 103 -> 98 us, the wide records it needs +12 us in the fill pass -- so float32
 // storage keeps the float32-exact VALU kernel unless boxattn_set_variant(11) asks for it.
+// float32 storage with 32 channels per head: binned_accumulate_f32_kernel (float32 MFMAs: exact like the VALU kernel)
+inline bool f32_mfma_ok(const Dims &d)
+{
+    // (opt-in: measured at C2 109 us against the VALU kernel's 102 on model-like inputs -- the matrix pipe is busy 63 us
+    // of them, 2-3 waves per SIMD do not keep it fed -- and 111 against 133 on uniformly random ones; + 6 us of wide fill)
+    return opt(kOptAccF32) == 2 && d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes &&
+           d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
+}
 template <typename ST, bool INST> inline bool mfma_accumulate(const Dims &d)
 {
     if (!BOXATTN_TUNE_ACC_MFMA || INST) return false;
     if (std::is_same<ST, bf16_t>::value) return true;
-    return std::is_same<ST, float>::value && d.C == 32 && g_variant == 11;
+    return std::is_same<ST, float>::value && d.C == 32 && (g_variant == 11 || f32_mfma_ok(d));
 }
 // flavours whose bin passes write 16-byte records {id, x, y, weight}
 template <typename ST, bool INST> inline bool wide_records(const Dims &d)
@@ -687,7 +696,7 @@ inline bool wide_workspace(bool is_bf16, const Dims &d)
     // variant changed after the size query finds the workspace too small and takes the fallback
     return is_bf16 ? BOXATTN_TUNE_ACC_MFMA != 0
                    : (BOXATTN_TUNE_WIDE_F32 != 0 ||
-                      (BOXATTN_TUNE_ACC_MFMA != 0 && d.C == 32 && g_variant == 11));
+                      (BOXATTN_TUNE_ACC_MFMA != 0 && d.C == 32 && (g_variant == 11 || f32_mfma_ok(d))));
 }
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 
@@ -1160,6 +1169,13 @@ void launch_accumulate_mfma(const ST *grad_out, const Dims &d, const BinPlan &pl
         if ((rec12 || opt(kOptAccTr) != 1) && accumulate_tr_ok<ST, C>(d)) {      // (12-byte records: this kernel only)
             launch_accumulate_tr(C, grad_out, go_bytes, plan, d.S, d.H, d.Lq, items, n_items, records, grad_value,
                                  partials, wg_per_slice, ns8, rec12, st);
+            return;
+        }
+    }
+    if constexpr (std::is_same<ST, float>::value && C == 32) {
+        if (g_variant != 11 && f32_mfma_ok(d)) {
+            launch_accumulate_f32(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
+                                  n_items, records, grad_value, partials, wg_per_slice, ns8, st);
             return;
         }
     }

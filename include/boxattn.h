@@ -357,6 +357,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *  18  12-byte bin records for bf16 box attention (footprint corner relative to the block + 16-bit fractions
  *      instead of float32 coordinates): 0 / 1 off (default), 2 on -- 2 % faster, but a weight is then exact to
  *      2^-17 ABSOLUTE instead of relative.  Set before *_fwd_train_* / the backward.
+ *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands
+ *      and accumulation, wide records): 0 / 1 off (default: measured slower on model-like inputs), 2 on.
+ *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  */

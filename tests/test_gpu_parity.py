@@ -237,6 +237,37 @@ def test_box_backward_algorithms(cfg, dtype, variant):
     close(ga, want[2], torch.float32, "grad_attn")
 
 
+OPT_ACC_F32 = 19        # boxattn_set_option: 2 = float32 accumulate on v_mfma_f32_32x32x2_f32 (opt-in)
+
+
+@pytest.mark.parametrize("with_plan", [False, True], ids=["own_binning", "forward_plan"])
+@pytest.mark.parametrize("cfg", [FAST_CFGS[0], FAST_CFGS[1], FAST_CFGS[4], FAST_CFGS[5], SEEDED[6]],
+                         ids=["0", "1", "4", "5", "6"])
+def test_float32_matrix_core_accumulate(cfg, with_plan):
+    """float32 grad_value (32 channels per head) from float32 MFMAs against the oracle at the float32 tolerance
+    and against the VALU kernel to summation-order rounding."""
+    from boxer_amd import _lib, ops
+    g = _seeded(*cfg, seed=37, lo=-0.2, hi=1.2)
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])
+    value, loc, attn = dev(g["value"], torch.float32), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
+    shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], torch.float32)
+    res = {}
+    for mode in (2, 1):
+        old = _lib.load().boxattn_set_option(OPT_ACC_F32, mode)
+        try:
+            if with_plan:
+                _, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
+                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)[0]
+            else:
+                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64)[0]
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().boxattn_set_option(OPT_ACC_F32, old)
+        res[mode] = gv
+        close(gv, want[0], torch.float32, "grad_value (float32 accumulate %d)" % mode)
+    assert (res[2] - res[1]).abs().max().item() <= 1e-5 * max(1.0, res[1].abs().max().item())
+
+
 OPT_REC12 = 18          # boxattn_set_option: 2 = 12-byte bin records for bf16 box attention (opt-in), 0 / 1 = 16-byte records
 
 
