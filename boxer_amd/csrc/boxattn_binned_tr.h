@@ -303,13 +303,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
 // 32 MFMAs of 64 cycles per round: the kernel is bound by the matrix pipe (61 us at C2 for 73 k rounds) instead of
 // the VALU kernel's list walk (103 us).  Wide records {id, x, y, weight} as the bf16 kernel.
 template <int C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void binned_accumulate_f32_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void binned_accumulate_f32_kernel(
     const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
     const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials)
 {
     static_assert(C == 32, "channels per head");
-    constexpr int BW = 8, PB = 32, R = 64;
+    constexpr int BW = 8, PB = 32, R = 64, RH = R / 2;
     constexpr int ROWB = C * 4;                    // bytes of one upstream-gradient row
     constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each (8)
     constexpr int RPP = 64 / LPR;                  // rows fetched per pass (8)
@@ -317,8 +317,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void bi
     constexpr int AP = PB + 1;                     // floats per A^T row: 32 pixels + the dump column
     constexpr int kBig = 1 << 20;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float gs[R * C];
-    __shared__ __attribute__((aligned(16))) float at[R * AP];
+    // LDS tiles for HALF a round (32 records): the matrix pipe needs four waves per SIMD to stay fed across the
+    // scatter / stage phases, and whole-round tiles (16.6 KB) allow two
+    __shared__ __attribute__((aligned(16))) float gs[RH * C];
+    __shared__ __attribute__((aligned(16))) float at[RH * AP];
 
     const int n_slices = plan.n_slices, workers = gridDim.x;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void bi
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, record of the K = 2 step
     const int n_it = n_items[2 * s];
 
-    for (int i = lane; i < R * AP; i += 64) at[i] = 0.f;
+    for (int i = lane; i < RH * AP; i += 64) at[i] = 0.f;
     wave_lds_sync();
 
     const __amdgpu_buffer_rsrc_t rs =
@@ -373,22 +375,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void bi
                 rows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, oj, 0, 0);
             }
         };
-        auto stage_rows = [&]() {
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps)
-                *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(gs) + (ps * 64 + lane) * 16) = rows[ps];
-        };
         int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R);
         fetch_rows(rec_c);
-        stage_rows();
         for (int rr = item.y; rr < item.z; rr += R) {
             const bool more = rr + R < item.z;     // wave-uniform
-            int4 rec_n2 = make_int4(-1, 0, 0, 0);
-            if (more) {
-                fetch_rows(rec_n);
-                rec_n2 = fetch_rec(rr + 2 * R);
-            }
-            // ---- lane = record: its <= 4 weights go to A^T[lane][pixel]
+            // ---- lane = record: its <= 4 weights
             const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
             float h_im, w_im;
             {
@@ -405,29 +396,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void bi
             const int r1 = (unsigned)(py + 1) < (unsigned)bh ? (py + 1) * BW : kBig;
             const int c0 = (unsigned)px < (unsigned)bw ? px : kBig;
             const int c1 = (unsigned)(px + 1) < (unsigned)bw ? px + 1 : kBig;
-            float *my = at + lane * AP;
+            float *my = at + (lane & (RH - 1)) * AP;
             const int slot[4] = {min(r0 + c0, PB), min(r0 + c1, PB), min(r1 + c0, PB), min(r1 + c1, PB)};
+            // ---- two half rounds of 32 records: stage their rows, scatter their weights, 16 K-steps of 2 records
 #pragma unroll
-            for (int k = 0; k < 4; ++k) my[slot[k]] = wk[k];
-            wave_lds_sync();
-            // ---- the product: 32 K-steps of 2 records
-            // (two accumulator chains: a dependent 32x32 MFMA waits for its predecessor's 64 cycles + latency)
+            for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int t = 0; t < R / 2; t += 2) {
-                const float g0 = gs[(2 * t + kb) * C + col], g1 = gs[(2 * t + 2 + kb) * C + col];
-                const float p0 = at[(2 * t + kb) * AP + col], p1 = at[(2 * t + 2 + kb) * AP + col];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, p0, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, p1, acc2, 0, 0, 0);
+                for (int ps = 0; ps < NPASS / 2; ++ps)
+                    *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(gs) + (ps * 64 + lane) * 16) = rows[hf * (NPASS / 2) + ps];
+                if ((lane >> 5) == hf) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) my[slot[k]] = wk[k];
+                }
+                wave_lds_sync();
+                if (hf == 1 && more) {             // the rows of this round are in LDS: request the next round's
+                    fetch_rows(rec_n);
+                }
+                // (two accumulator chains: a dependent 32x32 MFMA waits for its predecessor's 64 cycles + latency)
+#pragma unroll
+                for (int t = 0; t < RH / 2; t += 2) {
+                    const float g0 = gs[(2 * t + kb) * C + col], g1 = gs[(2 * t + 2 + kb) * C + col];
+                    const float p0 = at[(2 * t + kb) * AP + col], p1 = at[(2 * t + 2 + kb) * AP + col];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, p0, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, p1, acc2, 0, 0, 0);
+                }
+                wave_lds_sync();
+                if ((lane >> 5) == hf) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) my[slot[k]] = 0.f;
+                }
+                wave_lds_sync();
             }
-            wave_lds_sync();
-            // ---- clear this round's weights, stage the next round's rows
-#pragma unroll
-            for (int k = 0; k < 4; ++k) my[slot[k]] = 0.f;
             if (more) {
-                stage_rows();
-                rec_c = rec_n; rec_n = rec_n2;
+                rec_c = rec_n;
+                rec_n = fetch_rec(rr + 2 * R);
             }
-            wave_lds_sync();
         }
         // ---- store.  Lane = pixel `col`; its registers hold channels 8 g + 4 kb + 0..3.
 #pragma unroll

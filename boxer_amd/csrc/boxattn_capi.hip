@@ -672,8 +672,8 @@ template <typename ST> inline bool side_stream_worth(const Dims &) { return fals
 // float32 storage with 32 channels per head: binned_accumulate_f32_kernel (float32 MFMAs: exact like the VALU kernel)
 inline bool f32_mfma_ok(const Dims &d)
 {
-    // (opt-in: measured at C2 109 us against the VALU kernel's 102 on model-like inputs -- the matrix pipe is busy 63 us
-    // of them, 2-3 waves per SIMD do not keep it fed -- and 111 against 133 on uniformly random ones; + 6 us of wide fill)
+    // (opt-in: measured at C2 97 us against the VALU kernel's 102 on model-like inputs -- the matrix pipe is busy 63 us
+    // of them -- and 100 against 133 on uniformly random ones; + 6 us for the wide records in the fill pass)
     return opt(kOptAccF32) == 2 && d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes &&
            d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
 }
