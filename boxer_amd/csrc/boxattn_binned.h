@@ -354,14 +354,31 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_seg_kernel(int *__restr
                                                                     int *__restrict__ offsets,
                                                                     int4 *__restrict__ tmp,
                                                                     int4 *__restrict__ segtot,
-                                                                    BinPlan plan)
+                                                                    BinPlan plan, int *__restrict__ part = nullptr,
+                                                                    int fuse_wg = 0)
 {
+    // fuse_wg > 0 (few bin workgroups per slice -- the big maps with few queries have ONE): bin_scan_a_kernel's
+    // work is done here as well, as in bin_scan_kernel: one launch less in a chain of short kernels
     __shared__ int wsum[4][kScanThreads / 64];
     const int seg = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k = seg * kScanThreads + (int)threadIdx.x;
     const bool live = k < plan.nblk;
     int c = 0;
-    if (live) {
+    if (live && fuse_wg > 0) {
+        const int wps = (fuse_wg + kScanSub - 1) / kScanSub;
+        int *sp = part + (size_t)s * fuse_wg * plan.nblk + k;
+        for (int u = 0; u < kScanSub; ++u) {
+            subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;
+            int in_sub = 0;
+            const int w_hi = min(fuse_wg, (u + 1) * wps);
+            for (int w = u * wps; w < w_hi; ++w) {
+                const int t = sp[(size_t)w * plan.nblk];
+                sp[(size_t)w * plan.nblk] = in_sub;
+                in_sub += t;
+            }
+            c += in_sub;
+        }
+    } else if (live) {
         int t[kScanSub];
 #pragma unroll
         for (int u = 0; u < kScanSub; ++u) t[u] = subtot[((size_t)s * kScanSub + u) * plan.nblk + k];

@@ -912,7 +912,8 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
 #define BOXATTN_TUNE_SCAN_FUSE_WG 48   // up to this many bin workgroups per slice the block scan does kernel A's work too
                                        // (38 workgroups, the 300-query decoders: C3'' fp32 68 -> 61 us; 64, C2: binning 49 -> 61 us)
 #endif
-    const bool fuse_a = plan.nblk <= kScanThreads && w.n_wg <= BOXATTN_TUNE_SCAN_FUSE_WG;
+    // (big maps, multi-workgroup block scan: fused up to 8 bin workgroups per slice -- the 1 000-query BEV decoder has 1)
+    const bool fuse_a = plan.nblk <= kScanThreads ? w.n_wg <= BOXATTN_TUNE_SCAN_FUSE_WG : w.n_wg <= 8;
     if (!(stages & kBinScan)) {
     } else if (!fuse_a)
         hipLaunchKernelGGL(bin_scan_a_kernel,
@@ -923,7 +924,7 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
         const int nseg = (plan.nblk + kScanThreads - 1) / kScanThreads;
         int4 *tmp = (int4 *)(ws + w.scan_tmp), *segtot = tmp + (size_t)ns * plan.nblk;
         hipLaunchKernelGGL(bin_scan_seg_kernel, dim3(nseg, ns), dim3(kScanThreads), 0, st, subtot,
-                           offsets, tmp, segtot, plan);
+                           offsets, tmp, segtot, plan, part, fuse_a ? w.n_wg : 0);
         hipLaunchKernelGGL(bin_scan_emit_kernel, dim3(nseg, ns), dim3(kScanThreads), 0, st, offsets,
                            tmp, segtot, items, combos, n_items, plan);
     } else {
