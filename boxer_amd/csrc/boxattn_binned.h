@@ -172,6 +172,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
                 else touched_blocks(xy[u][k].x, xy[u][k].y, lv, blk);
                 // predicated, not redirected to a dump slot: same-address LDS atomics serialise
                 // per lane, a shared dump slot made this kernel 1.6x slower
+#ifndef BOXATTN_TUNE_COUNT_DUMP
+#define BOXATTN_TUNE_COUNT_DUMP 0      // count pass: unconditional atomics, unused candidates on a per-THREAD dump slot
+#endif
+                if constexpr (!FILL && BOXATTN_TUNE_COUNT_DUMP) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        atomicAdd(&hist[blk[j] >= 0 ? blk[j] : plan.nblk + 1 + (int)threadIdx.x], 1);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (blk[j] >= 0) {

@@ -884,7 +884,7 @@ inline void launch_binning_t(const float *loc, const float *w_sp, const Dims &d,
     int *offsets = (int *)(ws + w.offsets), *records = (int *)(ws + w.records);
     int4 *items = (int4 *)(ws + w.items), *combos = (int4 *)(ws + w.combos);
     const dim3 bgrid(w.n_wg, ns);
-    const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
+    const size_t bsh = ((size_t)plan.nblk + 1 + (BOXATTN_TUNE_COUNT_DUMP ? kBinThreads : 0)) * sizeof(int);
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);     // count + scan + fill
 #ifndef BOXATTN_TUNE_BIN_PT
 #define BOXATTN_TUNE_BIN_PT 4
