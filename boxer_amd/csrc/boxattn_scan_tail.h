@@ -35,9 +35,6 @@ constexpr int kScanThreads = 1024;     // one workgroup per slice walks the bloc
 // Results as the two kernels'.  Inter-workgroup hand-off (MI355X_MICROARCH.md, inter-workgroup
 // visibility): agent-scope (write-through) stores of the totals -> s_waitcnt vmcnt(0) -> __syncthreads
 // -> relaxed agent atomic (the ticket); the last arriver reads them with agent-scope loads.
-#ifndef BOXATTN_TUNE_TAIL_ACQUIRE
-#define BOXATTN_TUNE_TAIL_ACQUIRE 0
-#endif
 struct ScanTail {
     int *subtot, *offsets;
     int4 *items, *combos;
@@ -90,10 +87,6 @@ __device__ __forceinline__ void bin_scan_tail_body(const ScanTail t, int s, int 
     }
     __syncthreads();
     if (ticket != kScanSub - 1) return;                               // workgroup-uniform
-#if BOXATTN_TUNE_TAIL_ACQUIRE
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, BOXATTN_TUNE_TAIL_ACQUIRE == 2 ? "" : "agent");
-    __syncthreads();
-#endif
     // ---- the slice's block scan (bin_scan_kernel)
     int c[PER], nch[PER], sum[4] = {0, 0, 0, 0};
 #pragma unroll
