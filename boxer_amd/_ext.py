@@ -84,7 +84,8 @@ def load():
     spec = importlib.util.spec_from_file_location(MODULE_NAME, EXT_PATH, loader=loader)
     mod = importlib.util.module_from_spec(spec)
     loader.exec_module(mod)
-    if _lib.load().boxattn_abi_version() != _lib.ABI_VERSION:
+    # the header the module was COMPILED against vs the library that is loaded now
+    if getattr(mod, "compiled_abi_version", None) != _lib.load().boxattn_abi_version():
         raise RuntimeError("%s was built against another ABI of %s: rebuild (python setup.py "
                            "build_ext --inplace)" % (MODULE_NAME, _lib.LIB_NAME))
     sys.modules[MODULE_NAME] = mod

@@ -42,13 +42,16 @@ _SIGNATURES = {
     "instattn_bwd": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp],
 }
 _WS_SIGNATURES = {
-    # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, stream
-    "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _i, _vp],
-    "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _i, _vp],
-    # forward args + shapes_host, lsi_host, workspace, workspace_bytes, int *plan_built, stream
-    "boxattn_fwd_train": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp, ctypes.c_size_t, _vp, _vp],
+    # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, plan, plan_bytes, stream
+    "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                                       _vp],
+    "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
+                                                        ctypes.c_size_t, _vp],
+    # forward args + shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, int *plan_built, stream
+    "boxattn_fwd_train": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                                      _vp, _vp],
     "instattn_fwd_train": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
-                                                          _vp],
+                                                          ctypes.c_size_t, _vp, _vp],
 }
 _HL_SIGNATURES = {
     # forward args + shapes_host, lsi_host, stream
@@ -84,10 +87,11 @@ EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "
            "boxattn_fwd_grid_f32", "boxattn_fwd_grid_bf16", "boxattn_bwd_ws_grid_f32",
            "boxattn_bwd_ws_grid_bf16",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
+           "boxattn_plan_bytes", "boxattn_state_bytes",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def hipcc_path():
@@ -103,10 +107,31 @@ def _deps():
     return [d for d in deps if os.path.exists(d)]
 
 
+def _flags_stamp(extra_flags=()):
+    """The command-line flags of every translation unit: a change of flags rebuilds like a change of
+    sources (the -fno-slp-vectorize rule of boxattn_dense.hip is a correctness matter)."""
+    return repr((HIPCC_FLAGS, sorted(SOURCES.items()), list(extra_flags)))
+
+
+def _stamp_path(tag):
+    return os.path.join(BUILD_DIR, tag + ".flags")
+
+
+def _flags_changed(tag, extra_flags=()):
+    try:
+        with open(_stamp_path(tag)) as fh:
+            return fh.read() != _flags_stamp(extra_flags)
+    except OSError:
+        return True
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
+    # (a shipped library without a build directory is taken as it is)
+    if os.path.isdir(BUILD_DIR) and _flags_changed(os.path.basename(LIB_PATH)):
+        return True
     return any(os.path.getmtime(s) > built for s in _deps())
 
 
@@ -121,11 +146,12 @@ def build(force=False, verbose=False, extra_flags=(), out_path=None):
     tag = os.path.basename(out_path)
     os.makedirs(BUILD_DIR, exist_ok=True)
     newest = max(os.path.getmtime(d) for d in _deps())
+    stale_flags = _flags_changed(tag, extra_flags)
     procs, objs = [], []
     for src, flags in SOURCES.items():
         obj = os.path.join(BUILD_DIR, "%s.%s.o" % (tag, src))
         objs.append(obj)
-        if not (force or variant) and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        if not (force or variant or stale_flags) and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
             continue
         cmd = [hipcc_path()] + HIPCC_FLAGS + list(flags) + list(extra_flags) + [
             "-c", os.path.join(_CSRC, src), "-o", obj]
@@ -140,6 +166,8 @@ def build(force=False, verbose=False, extra_flags=(), out_path=None):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(out_path + ".tmp", out_path)
+    with open(_stamp_path(tag), "w") as fh:
+        fh.write(_flags_stamp(extra_flags))
     if not variant:
         global _lib
         _lib = None
@@ -190,8 +218,11 @@ def load():
     for name, args in list(_GRID_SIGNATURES.items()) + list(_POINTWISE_SIGNATURES.items()):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = _i
-    lib.boxattn_bwd_workspace_bytes.argtypes = [_i] * 8 + [_vp, _vp]
-    lib.boxattn_bwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.boxattn_state_bytes.argtypes = [_i, _i]
+    lib.boxattn_state_bytes.restype = ctypes.c_size_t
+    for name in ("boxattn_bwd_workspace_bytes", "boxattn_plan_bytes"):
+        getattr(lib, name).argtypes = [_i] * 8 + [_vp, _vp]
+        getattr(lib, name).restype = ctypes.c_size_t
     if lib.boxattn_abi_version() != ABI_VERSION:
         raise RuntimeError("ABI version mismatch in %s" % path)
     _lib = lib
@@ -203,19 +234,21 @@ def build_info():
 
 
 def set_variant(v):
-    """0 = auto, 1 = generic kernels only, 2 = fast atomic kernels only, 3 = binned backward
-    only (2 and 3 return an error when the shape is not eligible)."""
+    """0 = auto, 1 = generic kernels only, 2 = fast atomic kernels only, 3 = auto with the binned
+    backward required (2 and 3 return an error when the shape is not eligible)."""
     return load().boxattn_set_variant(int(v))
 
 
-OPTIONS = {"tile_shape": 0, "tile_rows": 1, "tile_margin_cap": 2, "tile_static_q16": 3,
-           "tile_ablate": 4, "qg_target": 5, "tile_fwd": 6, "qg_ablate": 7, "qg_waves": 8, "qg_bwd": 9,
-           "bin_chunk": 10}
+OPTIONS = {"bin_chunk": 10, "dense": 11, "dense_jit": 12, "dense_ref": 13, "riders": 15, "dense_fwd": 17,
+           "acc_f32": 19, "ride_shift": 20}
 
 
 def set_option(name, value):
     """Tuning knobs for A/B runs (include/boxattn.h: boxattn_set_option); returns the old value."""
-    return load().boxattn_set_option(OPTIONS[name], int(value))
+    old = load().boxattn_set_option(OPTIONS[name], int(value))
+    if old < 0:
+        raise KeyError(name)
+    return old
 
 
 def profile_begin():

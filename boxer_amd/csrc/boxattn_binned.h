@@ -19,7 +19,7 @@
 //   3. bin_kernel<fill>    same pass again, now writing the point ids into their bins.
 //   4. pointgrad2_kernel (boxattn_gather2.h): grad_loc / grad_weight, query-major.
 //   5. accumulate, one wavefront per work item, two formulations:
-//      binned_accumulate_mfma_kernel (boxattn_binned_mfma.h; bf16 box attention): a round of 64
+//      binned_accumulate_tr_kernel (boxattn_binned_tr.h; bf16 box attention): a round of 64
 //                          records x 32 pixels as a dense product on the matrix cores, from
 //                          wide records {id, x, y, weight};
 //      binned_accumulate_kernel (here; fp32 storage and instance attention): records ->
@@ -30,7 +30,10 @@
 //                          Either way: one plain coalesced row store per pixel in the storage
 //                          type; blocks cut into chunks (the coarse levels) write fp32 partial
 //                          tiles instead.
-//   6. combine_partials_kernel   sums the partial tiles of the chunked blocks.
+//   6. combine: the partial tiles of a chunked block are summed by the block's last chunk item to finish
+//                          (chunk_finish, boxattn_combine.h); combine_partials_kernel for plans too big for that.
+// In the training step the passes 1-3 are not launches of their own: count + scans ride in the forward
+// kernel's launch, fill in the point-gradient kernel's (boxattn_ride.h, boxattn_binpass.h).
 // No zero-fill, no conversion pass, no float atomics (run-to-run differences are limited to
 // the fp32 summation order inside a bin, which follows integer LDS atomics).
 //
@@ -42,175 +45,39 @@
 #include "boxattn_combine.h"
 #include "boxattn_binplan.h"
 #include "boxattn_scan_tail.h"
+#include "boxattn_binpass.h"
 
 namespace boxattn {
 
-#ifndef BOXATTN_TUNE_INTERLEAVE
-#define BOXATTN_TUNE_INTERLEAVE 1
-#endif
-
 // ---------------------------------------------------------------------------------------
-// 1 + 3: count / fill.  grid = (workgroups, slices), block kBinThreads, dynamic LDS nblk+1 ints.
+// 1 + 3: count / fill as launches of their own (a backward that plans for itself, maps too big for the
+//        riders).  grid = (workgroups, slices), block kBinThreads, dynamic LDS nblk ints.
 // ---------------------------------------------------------------------------------------
 #ifndef BOXATTN_TUNE_BIN_THREADS
 #define BOXATTN_TUNE_BIN_THREADS 512
 #endif
 constexpr int kBinThreads = BOXATTN_TUNE_BIN_THREADS;
-// WIDE records (bf16 box attention, boxattn_binned_mfma.h): {point id, x, y, attention weight}
-// instead of the id alone, so that the accumulate kernel reads everything but the upstream row
-// from its (coalesced) record stream instead of gathering two more 128-byte lines per record.
-// PT = 4 (P % 4 == 0, 16-byte aligned tensors): a thread takes four consecutive points of one
-// (query, level) with two 16-byte loads and one level lookup (count pass 13.5 -> 11.7 us);
-// PT = 1: any P.
-// REC12 (with FILL and WIDE): 12-byte records, see touched_blocks12() (boxattn_binplan.h).
-template <int BW, int BH, bool FILL, bool WIDE, bool INTERLEAVE, int PT, bool REC12 = false>
+template <int BW, int BH, bool FILL, bool WIDE, int PT>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restrict__ loc,
                                                   const float *__restrict__ w_sp, BinPlan plan,
-                                                  int H, int Lq, int P, int q_per_wg, int n_wg,
+                                                  int H, int Lq, int P, int q_per_wg, int n_wg, int interleave,
                                                   int *__restrict__ part,
                                                   const int *__restrict__ subtot,
                                                   const int *__restrict__ offsets,
-                                                  int *__restrict__ records,
-                                                  int *__restrict__ tickets = nullptr)
+                                                  int *__restrict__ records)
 {
-    // count pass of a training forward whose scans ride in the forward kernel (ScanTail): clear the
-    // slices' tickets.  (Not a hipMemsetAsync in front: a memset node as the first node of a captured
-    // graph left the kernels behind it reading stale upstream gradients on replay.)
-    if (!FILL && tickets && blockIdx.x == 0 && threadIdx.x == 0) tickets[blockIdx.y] = 0;
     // part[slice][workgroup][block]: after the count pass the number of records this workgroup
-    // has for the block; the scan kernel turns it into the workgroup's first slot inside the
-    // block's bin.  No global atomics anywhere in the binning (they cost ~20 us per pass:
-    // ~200 k single-lane atomics on 226 cache lines), and the record order is deterministic.
-    extern __shared__ int sh_bins[];
-    int *hist = sh_bins;
+    // has for the block; the scan turns it into the workgroup's first slot inside the block's bin.
     // grid = (n_wg, slices).  (Placing all workgroups of a slice on one XCD, so that the record
     // writes of a bin merge in one L2, changed nothing: the fill pass is bound by the bytes.)
+    extern __shared__ int sh_bins[];
+    __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane (no select chains)
     const int s = blockIdx.y, wg = blockIdx.x;
-    const int b = s / H, h = s % H;
-    const int LP = plan.L * P;
-    // INTERLEAVE (VALU accumulate kernel): workgroup w takes the queries w, w + n_wg,
-    // w + 2 n_wg, ...: every workgroup's records are then a uniform sample of the map, and so is
-    // any run of consecutive records of a bin.  That kernel works through a bin 64 records at a
-    // time with one lane per destination pixel; with contiguous query ranges a round's records
-    // came from neighbouring queries and piled up on a few pixels (longest per-pixel list 3.3x
-    // the mean; interleaved 2.1x; accumulate kernel 133 -> 103 us).
-    // MFMA accumulate kernel (a dense product, indifferent to the order): contiguous query
-    // ranges, whose records land in few bins, in runs -- 27 -> 24 us for the fill pass.
-    constexpr bool kInterleave = BOXATTN_TUNE_INTERLEAVE && INTERLEAVE;
-    const int q0 = kInterleave ? wg : wg * q_per_wg, qstep = kInterleave ? n_wg : 1;
-    const int n_q = kInterleave ? (q0 < Lq ? (Lq - q0 + qstep - 1) / qstep : 0)
-                                : max(0, min(q0 + q_per_wg, Lq) - q0);
-    const int n_pts = n_q * LP;
-    int *mypart = part + ((size_t)s * n_wg + wg) * plan.nblk;
-    __shared__ BinLevel s_lv[kMaxBinLevels];       // indexed per lane below (no select chains)
-
-    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    static_assert(PT == 1 || PT == 4, "points per thread and step");
-    constexpr int U = PT == 4 ? 2 : 4;            // groups of PT points per thread per step (loads in flight)
-    const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
-    const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
-    const int LPG = LP / PT, n_grp = n_q * LPG;               // groups per query, groups of this WG
-    const float rcp_lpg = 1.0f / (float)LPG, rcp_p = 1.0f / (float)P;
-    int *rec = records + (size_t)s * plan.rec_cap * (WIDE ? 4 : 1);
-    (void)n_pts;
-    // one step's points of this thread (clamped: every thread loads from valid addresses)
-    float2 xy[U][PT];
-    float wv[U][PT];
-    int lp0[U], ql[U];
-    auto load_step = [&](int g0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int g = min(g0 + u * kBinThreads, n_grp - 1);
-            int lg;
-            divmod_small(g, LPG, rcp_lpg, ql[u], lg);
-            lp0[u] = lg * PT;
-            const size_t base = pid0 + ql[u] * qstride + lp0[u];
-            if constexpr (PT == 4) {
-                const float4 *p4 = reinterpret_cast<const float4 *>(loc2 + base);
-                const float4 a = p4[0], c = p4[1];
-                xy[u][0] = make_float2(a.x, a.y); xy[u][1] = make_float2(a.z, a.w);
-                xy[u][2] = make_float2(c.x, c.y); xy[u][3] = make_float2(c.z, c.w);
-                if constexpr (FILL && WIDE) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(w_sp + base);
-                    wv[u][0] = w4.x; wv[u][1] = w4.y; wv[u][2] = w4.z; wv[u][3] = w4.w;
-                }
-            } else {
-                xy[u][0] = loc2[base];
-                if constexpr (FILL && WIDE) wv[u][0] = w_sp[base];
-            }
-            if constexpr (!(FILL && WIDE)) {
-#pragma unroll
-                for (int k = 0; k < PT; ++k) wv[u][k] = 0.f;
-            }
-        }
-    };
-    // The first step's loads go out BEFORE the level table / histogram set-up and its barrier: the
-    // set-up's own round trip (the fill pass reads three tables per block) then runs under theirs
-    // instead of in front of it (a workgroup usually has ONE step: a serial chain of two round trips).
-    if (n_grp > 0) load_step((int)threadIdx.x);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
-    }
-    const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in bin_scan_a_kernel
-    const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
-    for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads)
-        hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
-    __syncthreads();
-
-    for (int g0 = threadIdx.x; g0 < n_grp; g0 += kBinThreads * U) {
-        if (g0 != (int)threadIdx.x) load_step(g0);           // later steps (big workgroups only)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (g0 + u * kBinThreads >= n_grp) break;
-            const BinLevel lv = s_lv[(int)(((float)lp0[u] + 0.5f) * rcp_p)];   // level = lp / P
-#pragma unroll
-            for (int k = 0; k < PT; ++k) {
-                int blk[4];
-                unsigned rel[4] = {0u, 0u, 0u, 0u}, qf = 0u;
-                if constexpr (FILL && WIDE && REC12) touched_blocks12(xy[u][k].x, xy[u][k].y, lv, blk, rel, qf);
-                else touched_blocks(xy[u][k].x, xy[u][k].y, lv, blk);
-                // predicated, not redirected to a dump slot: same-address LDS atomics serialise
-                // per lane, a shared dump slot made this kernel 1.6x slower
-#ifndef BOXATTN_TUNE_COUNT_DUMP
-#define BOXATTN_TUNE_COUNT_DUMP 0      // count pass: unconditional atomics, unused candidates on a per-THREAD dump slot
-#endif
-                if constexpr (!FILL && BOXATTN_TUNE_COUNT_DUMP) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        atomicAdd(&hist[blk[j] >= 0 ? blk[j] : plan.nblk + 1 + (int)threadIdx.x], 1);
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (blk[j] >= 0) {
-#ifndef BOXATTN_TUNE_FILL_ABLATE
-#define BOXATTN_TUNE_FILL_ABLATE 0     // timing experiments only: 1 records into a 16 KiB window, 2 no record stores
-#endif
-                        int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
-                        if (BOXATTN_TUNE_FILL_ABLATE == 1) slot &= 1023;
-                        if (BOXATTN_TUNE_FILL_ABLATE == 2 && slot != -12345) continue;
-                        if constexpr (FILL) {
-                            const int id = ((q0 + ql[u] * qstep) << plan.lp_bits) | (lp0[u] + k);
-                            if constexpr (WIDE && REC12)
-                                reinterpret_cast<BinRec12 *>(rec)[slot] =
-                                    BinRec12{(int)((unsigned)id | ((rel[j] & 15u) << 24) | ((rel[j] >> 4) << 28)),
-                                             __float_as_int(wv[u][k]), (int)qf};
-                            else if constexpr (WIDE)
-                                reinterpret_cast<int4 *>(rec)[slot] =
-                                    make_int4(id, __float_as_int(xy[u][k].x),
-                                              __float_as_int(xy[u][k].y), __float_as_int(wv[u][k]));
-                            else
-                                rec[slot] = id;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (!FILL) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads) mypart[k] = hist[k];
+    bin_pass_body<kBinThreads, BW, BH, FILL, WIDE, PT>(sh_bins, s_lv, loc, w_sp, plan, H, Lq, P, q_per_wg, n_wg,
+                                                       interleave != 0, part, subtot, offsets, records, s, wg);
+    if constexpr (!FILL) {
+        int *mypart = part + ((size_t)s * n_wg + wg) * plan.nblk;
+        for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads) mypart[k] = sh_bins[k];
     }
 }
 
@@ -331,7 +198,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
             for (int j = 0; j < nch; ++j)
                 items[(size_t)s * plan.item_cap + (tot_items - 1 - (ex[1] + j))] =   // record range inside the slice
                     make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
-                              nch > 1 ? ex[2] + j : -1);          // .w = partial slot or -1
+                              nch > 1 ? (ex[2] + j) | (ex[3] << kItemSlotBits) : -1);   // .w: see kItemSlotBits
             if (nch > 1)
                 combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
         }
@@ -470,7 +337,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_emit_kernel(int *__rest
         for (int j = 0; j < nch; ++j)
             items[(size_t)s * plan.item_cap + (all[1] - 1 - (ex[1] + j))] =      // heaviest first
                 make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
-                          nch > 1 ? ex[2] + j : -1);
+                          nch > 1 ? (ex[2] + j) | (ex[3] << kItemSlotBits) : -1);
         if (nch > 1) combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
     }
     if (seg == 0 && threadIdx.x == 0) {
@@ -502,7 +369,7 @@ void binned_accumulate_kernel(
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
     const int *__restrict__ offsets, const int4 *__restrict__ items,
     const int *__restrict__ n_items, const int *__restrict__ records,
-    ST *__restrict__ grad_value, float *__restrict__ partials)
+    ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
 {
     constexpr int BW = 8, PB = 32;                      // blocks: up to 8 x 4 pixels
     constexpr int R = 64 * RPL;                        // records per round, RPL per lane
@@ -547,6 +414,7 @@ void binned_accumulate_kernel(
     // 4 entries per record + the lists' padding + the prefetch overrun of the last step
     __shared__ __attribute__((aligned(16))) Entry ent[4 * R + PB * (UNR - 1) + UNR];
     __shared__ int pcnt[PB + 1], poff[PB + 1];                             // pcnt[PB] = dump slot
+    __shared__ int last_flag;
 
     // Workgroup -> (slice, worker) so that all workers of a slice sit on ONE XCD (workgroup b
     // runs on XCD b % 8): a slice only reads the upstream-gradient / location / weight rows of
@@ -827,12 +695,15 @@ void binned_accumulate_kernel(
                 }
             }
         } else {
-            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + mypix) * C +
-                         half * CH;
+            // a chunk: fp32 partial tile; the block's last chunk to finish sums them (chunk_finish)
+            const bool publish = cc.tickets != nullptr;
+            const __amdgpu_buffer_rsrc_t tile =
+                partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
 #pragma unroll
             for (int c = 0; c < CH; c += 4)
-                *reinterpret_cast<float4 *>(dst + c) =
-                    make_float4(acc[c / 2].x, acc[c / 2].y, acc[c / 2 + 1].x, acc[c / 2 + 1].y);
+                partial_store(tile, (unsigned)((mypix * C + half * CH + c) * 4),
+                              make_float4(acc[c / 2].x, acc[c / 2].y, acc[c / 2 + 1].x, acc[c / 2 + 1].y), publish);
+            if (publish) chunk_finish<ST, C>(cc, partials, lv.start, lv.W, S, H, grad_value, s, item.w, lane, &last_flag);
         }
     }
 }

@@ -1,9 +1,9 @@
-// The matrix-core accumulate of the destination-binned backward (boxattn_binned_mfma.h: one round of
-// 64 records against the 32 pixels of a block is the product grad_value^T[c][pixel] += G^T[c][k] A^T[k][pixel])
-// for bf16 storage, rebuilt around the instruction count.  The SQ counters of round 3
-// show every kernel of the step retiring one instruction per SIMD every ~4 cycles whatever its type --
-// scalar instructions included -- so the 420 instructions binned_accumulate_mfma_kernel issues per round
-// ARE its 50 us.  Where they went, and what replaces them:
+// The matrix-core accumulate of the destination-binned backward for bf16 storage: one round of 64 records
+// against the 32 pixels of a block is the product grad_value^T[c][pixel] += G^T[c][k] A^T[k][pixel] on
+// v_mfma_f32_32x32x16_bf16 (A split into two bf16 terms), built around the instruction count.  The SQ
+// counters of round 3 show every kernel of the step retiring one instruction per SIMD every
+// ~4 cycles whatever its type -- scalar instructions included -- so the 420 instructions the first version
+// of this kernel (rounds 1-2) issued per round WERE its 50 us.  Where they went, and what replaces them:
 //
 //   * G^T staging (~70): the gathered upstream rows were transposed in registers (DPP swaps + v_perm) and
 //     written as dwords, because both MFMA operands want their K (= record) index contiguous per lane.
@@ -22,11 +22,9 @@
 //   * the store: lanes l and l + 32 exchange half of their packed rows with v_permlane32_swap (4
 //     instructions) instead of 4 ds_bpermute + 12 selects.
 //
-// Same records, same items, same results (the order of the float32 products inside a weight differs:
-// (hh a) hw instead of (hh hw) a) as binned_accumulate_mfma_kernel, which stays for float32 storage
-// (variant 11) and as the A/B partner (boxattn_set_option(16, 1)).
 #pragma once
 #include "boxattn_binplan.h"
+#include "boxattn_combine.h"
 
 namespace boxattn {
 
@@ -46,14 +44,11 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned short *base, unsig
     return __builtin_bit_cast(uint2, v);
 }
 
-// REC12: 12-byte records (boxattn_binplan.h touched_blocks12: footprint corner relative to the block, 16-bit
-// fractions) instead of the 16-byte {id, x, y, weight}: 25 % less of the stream the fill pass writes and this
-// kernel reads (the fill pass is bound by exactly those bytes), and no locate() per record here.
-template <typename ST, int C, bool REC12>
+template <typename ST, int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BOXATTN_TUNE_TR_WPE : 1))) void binned_accumulate_tr_kernel(
     const ST *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
-    const int *__restrict__ records, ST *__restrict__ grad_value, float *__restrict__ partials)
+    const int *__restrict__ records, ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
 {
     static_assert(sizeof(ST) == 2, "bf16 storage");
     static_assert(C == 16 || C == 32 || C == 64, "channels per head");
@@ -72,6 +67,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) unsigned short gs[NCB * GPL / 2];
     __shared__ __attribute__((aligned(16))) unsigned short at[(PB + 1) * AS];
+    __shared__ int last_flag;
 
     // workgroup -> (slice, worker): all workers of a slice on one XCD (see binned_accumulate_kernel)
     const int n_slices = plan.n_slices, workers = gridDim.x;
@@ -115,9 +111,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
             if (k == bg.level) { lvH = plan.lv[k].H; lvW = plan.lv[k].W; lv_start = plan.lv[k].start; }
         const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
         const float Hf = (float)lvH, Wf = (float)lvW;
-        // (a slice's record region is sized for 16-byte records either way)
         const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
-        const BinRec12 *rec12 = reinterpret_cast<const BinRec12 *>(rec);
         tr_f32x16 acc[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -132,15 +126,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
         constexpr unsigned kNoRow = 0x80000000u;
         auto fetch_rec = [&](int rr) -> int4 {
             if (rr + lane >= item.z) return make_int4(-1, 0, 0, 0);
-            if constexpr (REC12) {
-                const BinRec12 r3 = rec12[rr + lane];
-                return make_int4(r3.w0, r3.w1, r3.w2, 0);
-            } else {
-                return rec[rr + lane];
-            }
+            return rec[rr + lane];
         };
         auto fetch_rows = [&](const int4 &r, u32x4 (&rows)[NPASS]) {
-            const unsigned id = REC12 ? (unsigned)r.x & 0xffffffu : (unsigned)r.x;
+            const unsigned id = (unsigned)r.x;
             const unsigned off = r.x < 0 ? kNoRow : __umul24(id >> plan.lp_bits, q_stride) + slice_off;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
@@ -167,28 +156,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
                 rec_n3 = fetch_rec(rr + 3 * R);
             }
             // ---- lane = record: its <= 4 weights go to A^T[pixel][lane] as hi + lo bf16
-            float lh, lw, a;
-            int py, px;                             // footprint corner relative to the block; idle lanes: outside
-            if constexpr (REC12) {
-                a = __int_as_float(rec_c.y);
-                lw = (float)((unsigned)rec_c.z & 0xffffu) * (1.f / 65536.f);
-                lh = (float)((unsigned)rec_c.z >> 16) * (1.f / 65536.f);
-                px = (int)(((unsigned)rec_c.x >> 24) & 15u) - 1;
-                py = rec_c.x >= 0 ? (int)(((unsigned)rec_c.x >> 28) & 7u) - 1 : -2;
-            } else {
-                const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z);
-                a = __int_as_float(rec_c.w);
-                float h_im, w_im;
-                {
+            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
+            float h_im, w_im;
+            {
 #pragma clang fp contract(off)                   // two roundings, as in locate()
-                    h_im = y * Hf - 0.5f;
-                    w_im = x * Wf - 0.5f;
-                }
-                const float yf = floorf(h_im), xf = floorf(w_im);
-                lh = h_im - yf; lw = w_im - xf;
-                py = rec_c.x >= 0 ? (int)yf - oy : -2;
-                px = (int)xf - ox;
+                h_im = y * Hf - 0.5f;
+                w_im = x * Wf - 0.5f;
             }
+            const float yf = floorf(h_im), xf = floorf(w_im);
+            const float lh = h_im - yf, lw = w_im - xf;
+            // footprint corner relative to the block; idle lanes: outside
+            const int py = rec_c.x >= 0 ? (int)yf - oy : -2, px = (int)xf - ox;
             const float hh = 1.f - lh, hw = 1.f - lw;
             const float ha = hh * a, la = lh * a;
             const float w0 = ha * hw, w1 = ha * lw, w2 = la * hw, w3 = la * lw;
@@ -278,17 +256,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
                 if (live && c_hi < C) *reinterpret_cast<u32x4 *>(dst + c_hi) = piece_hi;
             }
         } else {
-            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + col) * C;
+            // a chunk: fp32 partial tile; the block's last chunk to finish sums them (chunk_finish)
+            const bool publish = cc.tickets != nullptr;
+            const __amdgpu_buffer_rsrc_t tile =
+                partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c = cb * 32 + 8 * g4 + 4 * kb;
                     if (c < C)
-                        *reinterpret_cast<float4 *>(dst + c) =
-                            make_float4(acc[cb][4 * g4], acc[cb][4 * g4 + 1], acc[cb][4 * g4 + 2],
-                                        acc[cb][4 * g4 + 3]);
+                        partial_store(tile, (unsigned)((col * C + c) * 4),
+                                      make_float4(acc[cb][4 * g4], acc[cb][4 * g4 + 1], acc[cb][4 * g4 + 2],
+                                                  acc[cb][4 * g4 + 3]), publish);
                 }
+            if (publish) chunk_finish<ST, C>(cc, partials, lv_start, lvW, S, H, grad_value, s, item.w, lane, &last_flag);
         }
     }
 }
@@ -306,7 +288,7 @@ template <int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void binned_accumulate_f32_kernel(
     const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
-    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials)
+    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
 {
     static_assert(C == 32, "channels per head");
     constexpr int BW = 8, PB = 32, R = 64, RH = R / 2;
@@ -321,6 +303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bi
     // scatter / stage phases, and whole-round tiles (16.6 KB) allow two
     __shared__ __attribute__((aligned(16))) float gs[RH * C];
     __shared__ __attribute__((aligned(16))) float at[RH * AP];
+    __shared__ int last_flag;
 
     const int n_slices = plan.n_slices, workers = gridDim.x;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -446,11 +429,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bi
                     *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) =
                         make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
         } else {
-            float *dst = partials + (((size_t)s * plan.pslot_cap + item.w) * PB + col) * C;
+            const bool publish = cc.tickets != nullptr;
+            const __amdgpu_buffer_rsrc_t tile =
+                partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) =
-                    make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                partial_store(tile, (unsigned)((col * C + 8 * g4 + 4 * kb) * 4),
+                              make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]), publish);
+            if (publish) chunk_finish<float, C>(cc, partials, lv_start, lvW, S, H, grad_value, s, item.w, lane, &last_flag);
         }
     }
 }

@@ -12,7 +12,6 @@ struct BinLevel {
     int nbx, nby;         // blocks along x / y
     int blk0;             // first block id of this level inside a slice
     unsigned mw, mh;      // floor(2^32 / W) + 1, floor(2^32 / H) + 1 (0 for sizes <= 1): blk_of()
-    unsigned mnx, mny;    // floor(2^32 / nbx) + 1, floor(2^32 / nby) + 1: blk_lo_magic() (0: the host found it inexact)
 };
 
 // Blocks are a BALANCED partition of the map: block column c covers
@@ -28,12 +27,6 @@ __device__ __forceinline__ int blk_of(int x, int nb, unsigned magic)
 }
 // first coordinate of block c: ceil(c size / nb)
 __device__ __forceinline__ int blk_lo(int c, int size, int nb) { return (c * size + nb - 1) / nb; }
-
-// blk_lo() by multiply-high (the host checks every block index of the level against blk_lo)
-__device__ __forceinline__ int blk_lo_magic(int c, int size, int nb, unsigned magic)
-{
-    return (int)__umulhi((unsigned)(__mul24(c, size) + nb - 1), magic);
-}
 
 struct BinPlan {
     int L;
@@ -81,43 +74,6 @@ __device__ __forceinline__ void touched_blocks(float x, float y, const BinLevel 
     blk[1] = inside && cb != ca ? base_a + cb : -1;
     blk[2] = inside && rb != ra ? base_b + ca : -1;
     blk[3] = inside && rb != ra && cb != ca ? base_b + cb : -1;
-}
-
-struct __attribute__((aligned(4))) BinRec12 { int w0, w1, w2; };
-// 12-byte records {id | px + 1 << 24 | py + 1 << 28, attention weight, qlw | qlh << 16} of the matrix-core accumulate
-// (boxattn_binned_tr.h): the footprint's top-left corner RELATIVE to the destination block (px in [-1, 7], py in
-// [-1, 3]) and the bilinear fractions as 16-bit fixed point -- the weights are split into two bf16 terms there
-// anyway (2^-17 relative), so 2^-17 absolute on a fraction changes nothing that is kept.  Same blocks as
-// touched_blocks(); rel[j] = px + 1 | (py + 1) << 4 for candidate j, qf = round(lw 65536) | round(lh 65536) << 16.
-__device__ __forceinline__ void touched_blocks12(float x, float y, const BinLevel &lv, int (&blk)[4],
-                                                 unsigned (&rel)[4], unsigned &qf)
-{
-    float h_im, w_im;
-    {
-#pragma clang fp contract(off)                   // two roundings, as in locate()
-        h_im = y * (float)lv.H - 0.5f;
-        w_im = x * (float)lv.W - 0.5f;
-    }
-    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W &&
-                        lv.H > 0 && lv.W > 0;
-    const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
-    const float hf = floorf(hs), wf = floorf(ws);
-    const int y0 = (int)hf, x0 = (int)wf;
-    const unsigned qlh = min((unsigned)((hs - hf) * 65536.f + 0.5f), 65535u);
-    const unsigned qlw = min((unsigned)((ws - wf) * 65536.f + 0.5f), 65535u);
-    qf = qlw | (qlh << 16);
-    const int ra = blk_of(max(y0, 0), lv.nby, lv.mh), rb = blk_of(min(y0 + 1, lv.H - 1), lv.nby, lv.mh);
-    const int ca = blk_of(max(x0, 0), lv.nbx, lv.mw), cb = blk_of(min(x0 + 1, lv.W - 1), lv.nbx, lv.mw);
-    const int base_a = lv.blk0 + ra * lv.nbx, base_b = lv.blk0 + rb * lv.nbx;
-    blk[0] = inside ? base_a + ca : -1;
-    blk[1] = inside && cb != ca ? base_a + cb : -1;
-    blk[2] = inside && rb != ra ? base_b + ca : -1;
-    blk[3] = inside && rb != ra && cb != ca ? base_b + cb : -1;
-    const unsigned pya = (unsigned)(y0 - blk_lo_magic(ra, lv.H, lv.nby, lv.mny) + 1);
-    const unsigned pyb = (unsigned)(y0 - blk_lo_magic(rb, lv.H, lv.nby, lv.mny) + 1);
-    const unsigned pxa = (unsigned)(x0 - blk_lo_magic(ca, lv.W, lv.nbx, lv.mnx) + 1);
-    const unsigned pxb = (unsigned)(x0 - blk_lo_magic(cb, lv.W, lv.nbx, lv.mnx) + 1);
-    rel[0] = pxa | (pya << 4); rel[1] = pxb | (pya << 4); rel[2] = pxa | (pyb << 4); rel[3] = pxb | (pyb << 4);
 }
 
 }  // namespace boxattn

@@ -29,7 +29,7 @@
 // the L2 -> L1 traffic is the gather kernel's, and that traffic is what bounds both.)
 #pragma once
 #include "boxattn_device.h"
-#include "boxattn_combine.h"      // CombineTail: the combine step's workers ride in this launch too
+#include "boxattn_binpass.h"      // the backward's fill riders sit in the point-gradient kernel's launch
 #include "boxattn_dense_plan.h"
 
 namespace boxattn {
@@ -85,7 +85,6 @@ struct DenseTileId {
     int lq;                  // query level, -1: no tile
     unsigned b;
     int ty, tx, h;
-    int group;               // tile index mod kDenseGroups (DenseBin)
 };
 struct DenseMap { int H, W, start; };                   // what the kernel keeps of a level
 template <int L> struct DenseHot {
@@ -123,7 +122,6 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
         first += cnt;
     }
     t.lq = lq;
-    t.group = (int)(ti & (unsigned)(kDenseGroups - 1));
     const int lqc = max(lq, 0);
     const DenseLevel q = pl.lv[lqc];                       // the reads at a computed offset: one batch
 #pragma unroll
@@ -350,95 +348,25 @@ __device__ __forceinline__ void dense_corner_sums(const DensePoint &s, const Den
 
 constexpr int kDenseResFloats = 16 * 16 * 3;       // per wave: the results of 16 queries x 16 points
 
-// The workgroup's share of the bin records: counts of the slice's blocks in an LDS table (one int per
-// block, dynamic LDS), one global atomic per touched block.
-__device__ __forceinline__ void dense_tab_zero(int *tab, int nblk)
-{
-    for (int k = threadIdx.x; k < nblk; k += 256) tab[k] = 0;
-}
-// The blocks a point touches (touched_blocks() of boxattn_binplan.h on the slimmer level description:
-// blocks are 8 x 4 pixels in a balanced partition, nbx = ceil(W / 8), nby = ceil(H / 4)).
-__device__ __forceinline__ void dense_touched_blocks(float2 xy, const DenseMap &T, const DenseBinLevel &bl,
-                                                     int (&blk)[4])
-{
-    BinLevel lv;
-    lv.H = T.H; lv.W = T.W; lv.start = T.start;
-    lv.nbx = (T.W + 7) >> 3; lv.nby = (T.H + 3) >> 2;
-    lv.blk0 = bl.blk0; lv.mw = bl.mw; lv.mh = bl.mh;
-    touched_blocks(xy.x, xy.y, lv, blk);
-}
-// += 1 on the table entry of every block the point touches; the old values (< 256: a workgroup has 256
-// points per level) are the point's ranks, packed into one register
-__device__ __forceinline__ unsigned dense_tab_add(int *tab, float2 xy, const DenseMap &T, const DenseBinLevel &bl,
-                                                  bool live)
-{
-    int blk[4];
-    dense_touched_blocks(xy, T, bl, blk);
-    unsigned ranks = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (live && blk[j] >= 0) ranks |= (unsigned)atomicAdd(&tab[blk[j]], 1) << (8 * j);      // LDS
-    return ranks;
-}
-
-// counts[slice][block] += the records of this (tile, head)
 template <int L>
-__global__ __launch_bounds__(256) void dense_count_kernel(const float *__restrict__ loc, DensePlan pl,
-                                                          DenseBin bin)
-{
-    constexpr int P = 4, LP = L * P;
-    extern __shared__ int dense_tab[];
-    const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    DenseHot<L> hot;
-    DenseMap Q;
-    DenseWin wrow[L];
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q, wrow);
-    if (t.lq < 0) return;                                          // workgroup-uniform
-    const int qi = lane >> 2, p = lane & 3;
-    const int qy = t.ty * kDenseTile + (wv >> 1) * kDenseSub + (qi >> 2);
-    const int qx = t.tx * kDenseTile + (wv & 1) * kDenseSub + (qi & 3);
-    const bool vq = qy < Q.H && qx < Q.W;
-    const unsigned q = (unsigned)(Q.start + min(qy, Q.H - 1) * Q.W + min(qx, Q.W - 1));
-    const unsigned pt0 = ((t.b * (unsigned)hot.Lq + q) * (unsigned)hot.H + (unsigned)t.h) * (unsigned)LP;
-    const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
-    float2 xy[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) xy[l] = loc2[pt0 + l * P + p];
-    dense_tab_zero(dense_tab, bin.nblk);
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < L; ++l) dense_tab_add(dense_tab, xy[l], hot.lv[l], bin.lv[l], vq);
-    __syncthreads();
-    int *mine = bin.part + ((size_t)(t.b * (unsigned)hot.H + (unsigned)t.h) * kDenseGroups + t.group) * bin.nblk;
-    for (int k = threadIdx.x; k < bin.nblk; k += 256) {
-        const int c = dense_tab[k];
-        if (c > 0) atomicAdd(mine + k, c);
-    }
-}
-
-template <int L, bool FILL>
 __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
     const bf16_t *__restrict__ grad_out, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    DensePlan pl, unsigned value_bytes, unsigned tile_blocks, CombineTail ct, DenseBin bin)
+    DensePlan pl, unsigned value_bytes, BinRide ride)
 {
     constexpr int C = 32, P = 4, LP = L * P;
     __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
-    extern __shared__ int dense_tab[];                             // FILL: one counter per block of the slice
     static_assert(4 * kDenseResFloats * sizeof(float) <= sizeof(win_lds), "the result tiles reuse the window buffer");
+    static_assert(kRideLdsInts * sizeof(int) <= sizeof(win_lds), "so do the riders");
     // (the wave index as a scalar: everything per window row -- row index, clamps, byte offsets, the
     // "row exists" branches -- is then scalar code; derived from threadIdx in a vector register it was
     // ~25 vector instructions, a v_readfirstlane and an exec-mask branch per row)
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    if (blockIdx.x >= tile_blocks) {                  // the appended combine workgroups (pointgrad2_kernel)
-        if (ct.workers > 0) {
-            const int w = (int)((blockIdx.x - tile_blocks) * 4 + wv);
-            const int s = w / ct.workers;
-            if (s < ct.plan.n_slices)
-                combine_partials_body<bf16_t, C>(ct.combos, ct.n_items, ct.partials, ct.plan, pl.S, pl.H,
-                                                 static_cast<bf16_t *>(ct.grad_value), s, w % ct.workers,
-                                                 ct.workers, lane);
-        }
+    // the backward's fill pass rides in this launch (boxattn_ride.h): rider workgroups write the bin
+    // records while the tiles' workgroups compute -- the one waits on memory, the other on issue slots
+    const RideRole role = ride_role(blockIdx.x, ride.grid);
+    if (role.rider) {
+        bin_fill_ride<256>(ride, role.id, reinterpret_cast<int *>(win_lds));
         return;
     }
 #if BOXATTN_DENSE_DEBUG == 2
@@ -454,13 +382,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     DenseHot<L> hot;
     DenseMap Q;
     DenseWin wrow[L];
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x, hot, Q, wrow);
+    const DenseTileId t = dense_tile_of_block<L>(pl, role.id, hot, Q, wrow);
     if (t.lq < 0) return;                                          // workgroup-uniform
     const int H = hot.H, h = t.h;
-    if constexpr (FILL) {
-        dense_tab_zero(dense_tab, bin.nblk);
-        __syncthreads();                   // (early: every wave is here within a few hundred cycles)
-    }
 
     // ---- lane -> (query of the wave's 4x4 sub-tile, point)
     const int qi = lane >> 2, p = lane & 3;
@@ -494,36 +418,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DENSE_STAMP();                                                 // everything has arrived
 #endif
-    // FILL: the ranks of the lane's points in their bins (LDS atomics) behind the staging stores
     dense_stage_commit<L>(lane, wv, win_lds, hot.lv, win, stage);
-    unsigned ranks[FILL ? L : 1];          // (after the staging stores: their 64 registers are free again)
-    if constexpr (FILL) {
-#pragma unroll
-        for (int l = 0; l < L; ++l) ranks[l] = dense_tab_add(dense_tab, xy[l], hot.lv[l], bin.lv[l], vq);
-    }
-    __syncthreads();                       // windows (and block counts) complete
+    __syncthreads();                       // windows complete
     DENSE_STAMP();
-    // FILL: one global atomic per block this workgroup has records for -> the workgroup's first slot in
-    // the bin.  Requested here, needed after the levels: the round trip runs under the arithmetic.
-    constexpr int NE = kDenseFillMaxBlocks / 256;
-    int e_base[FILL ? NE : 1];                                     // -1: no records of mine in the block
-    const unsigned slice = t.b * (unsigned)H + (unsigned)h;
-    if constexpr (FILL) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int k = (int)threadIdx.x + 256 * i;
-            const int cnt = k < bin.nblk ? dense_tab[k] : 0;
-            e_base[i] = -1;
-            if (cnt > 0) {
-                // first slot of the group in the bin (bin_kernel's fill: sub-range prefix + sub-range start
-                // + bin start), then this workgroup's share of the group's run
-                constexpr int wps = (kDenseGroups + kDenseScanSub - 1) / kDenseScanSub;
-                const size_t gk = ((size_t)slice * kDenseGroups + t.group) * bin.nblk + k;
-                e_base[i] = bin.part[gk] + bin.subtot[((size_t)slice * kDenseScanSub + t.group / wps) * bin.nblk + k] +
-                            bin.offsets[(size_t)slice * (bin.nblk + 1) + k] + atomicAdd(bin.cursor + gk, cnt);
-            }
-        }
-    }
 
     float ga[L], gx[L], gy[L];
 #pragma unroll
@@ -544,31 +441,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     // ---- results: lane (q, p) holds its point on every level; memory wants, per (query, head),
     //      [level][point] runs -- transposed through (wave-private) LDS so that lane (q, j) writes
     //      level j's 4 points as 16 + 32 contiguous bytes (whole 64- / 128-byte runs per query)
-    if constexpr (FILL) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i)
-            if (e_base[i] >= 0) dense_tab[(int)threadIdx.x + 256 * i] = e_base[i];
-    }
     __syncthreads();                                               // every wave is done with the windows
-    if constexpr (FILL) {                                          // the records: {id, x, y, weight}
-        int4 *rec = reinterpret_cast<int4 *>(bin.records) + (size_t)slice * bin.rec_cap;
-        const unsigned q_in_image = q;                             // record id = (query << lp_bits) | (level P + point)
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            // (recomputed, not kept from the ranking: 16 block ids live across the levels would cost the
-            // kernel a wave per SIMD; the opaque copy keeps the compiler from merging the two)
-            float2 pxy = xy[l];
-            asm volatile("" : "+v"(pxy.x), "+v"(pxy.y));
-            int blk[4];
-            dense_touched_blocks(pxy, hot.lv[l], bin.lv[l], blk);
-            const int id = (int)((q_in_image << bin.lp_bits) | (unsigned)(l * P + p));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (vq && blk[j] >= 0)
-                    rec[dense_tab[blk[j]] + (int)((ranks[l] >> (8 * j)) & 255u)] =
-                        make_int4(id, __float_as_int(pxy.x), __float_as_int(pxy.y), __float_as_int(a[l]));
-        }
-    }
     float *res = reinterpret_cast<float *>(win_lds) + wv * kDenseResFloats;
     float *res_a = res + qi * LP, *res_xy = res + 16 * LP + qi * LP * 2;
 #pragma unroll
@@ -590,7 +463,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DENSE_STAMP();
     if (pl.dbg && lane == 0) {
-        float *o = pl.dbg + ((size_t)blockIdx.x * 4 + wv) * 20;
+        float *o = pl.dbg + ((size_t)role.id * 4 + wv) * 20;
         o[0] = (float)t.lq;
         o[1] = (float)(unsigned)(ts[0] & 0xffffffu);
         for (int i = 1; i < ts_n; ++i) o[1 + i] = (float)(unsigned)(ts[i] - ts[0]);

@@ -9,38 +9,23 @@
 
 namespace boxattn {
 
-void launch_dense_count(const float *loc, const DensePlan &dp, const DenseBin &bin, hipStream_t st)
+// rider workgroups of a launch: the caller sets ride.grid.n_riders / .shift, the rest follows from the grid
+static BinRide place_riders(BinRide ride, unsigned own_blocks, unsigned *total)
 {
-    const unsigned blocks = dense_blocks(dp);
-    const size_t lds = (size_t)bin.nblk * sizeof(int);
-#define BOXATTN_DENSE_CNT(LV_)                                                                      \
-    case LV_:                                                                                       \
-        hipLaunchKernelGGL((dense_count_kernel<LV_>), dim3(blocks), dim3(256), lds, st, loc, dp, bin); \
-        break;
-    switch (dp.L) {
-        BOXATTN_DENSE_CNT(1) BOXATTN_DENSE_CNT(2) BOXATTN_DENSE_CNT(3) BOXATTN_DENSE_CNT(4)
-    }
-#undef BOXATTN_DENSE_CNT
+    ride.grid = ride_grid(ride.grid.n_riders, own_blocks, ride.grid.shift, total);
+    return ride;
 }
 
 void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float *attn,
                             const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
-                            float *grad_attn, unsigned value_bytes, hipStream_t st,
-                            const CombineTail &tail, const DenseBin &bin)
+                            float *grad_attn, unsigned value_bytes, hipStream_t st, const BinRide &ride_in)
 {
-    const unsigned tail_blocks = tail.workers > 0 ? (unsigned)(tail.workers * tail.plan.n_slices + 3) / 4 : 0;
-    const unsigned blocks = dense_blocks(dp);
-    const size_t lds = bin.on ? (size_t)bin.nblk * sizeof(int) : 0;
+    unsigned total = 0;
+    const BinRide ride = place_riders(ride_in, dense_blocks(dp), &total);
 #define BOXATTN_DENSE_PG(LV_)                                                                           \
     case LV_:                                                                                           \
-        if (bin.on)                                                                                     \
-            hipLaunchKernelGGL((pointgrad_dense_kernel<LV_, true>), dim3(blocks + tail_blocks), dim3(256), lds, \
-                               st, value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes,   \
-                               blocks, tail, bin);                                                      \
-        else                                                                                            \
-            hipLaunchKernelGGL((pointgrad_dense_kernel<LV_, false>), dim3(blocks + tail_blocks), dim3(256), 0, \
-                               st, value, loc, attn, grad_out, grad_loc, grad_attn, dp, value_bytes,   \
-                               blocks, tail, bin);                                                      \
+        hipLaunchKernelGGL((pointgrad_dense_kernel<LV_>), dim3(total), dim3(256), 0, st, value, loc, attn, \
+                           grad_out, grad_loc, grad_attn, dp, value_bytes, ride);                      \
         break;
     switch (dp.L) {
         BOXATTN_DENSE_PG(1) BOXATTN_DENSE_PG(2) BOXATTN_DENSE_PG(3) BOXATTN_DENSE_PG(4)
@@ -49,15 +34,14 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
 }
 
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, const ScanTail *scan_tail, hipStream_t st)
+                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride_in, hipStream_t st)
 {
-    const unsigned blocks = dense_blocks(dp);
-    const ScanTail sct = scan_tail ? *scan_tail : ScanTail{};
-    const unsigned lead = scan_tail ? (unsigned)(sct.plan.n_slices * kScanSub) : 0u;    // in FRONT of the grid
+    unsigned total = 0;
+    const BinRide ride = place_riders(ride_in, dense_blocks(dp), &total);
 #define BOXATTN_DENSE_FWD(LV_)                                                                       \
     case LV_:                                                                                        \
-        hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(blocks + lead), dim3(256), 0, st, value, loc, attn, out, \
-                           dp, value_bytes, lead, sct);                                              \
+        hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(total), dim3(256), 0, st, value, loc, attn, out, \
+                           dp, value_bytes, ride);                                                   \
         break;
     switch (dp.L) {
         BOXATTN_DENSE_FWD(1) BOXATTN_DENSE_FWD(2) BOXATTN_DENSE_FWD(3) BOXATTN_DENSE_FWD(4)
@@ -67,26 +51,27 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
 
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
                           int H, int Lq, const int4 *items, const int *n_items, const int *records,
-                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, bool rec12, hipStream_t st)
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc,
+                          hipStream_t st)
 {
-#define BOXATTN_ACC_TR(C_, R_)                                                                          \
-    hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_, R_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
+#define BOXATTN_ACC_TR(C_)                                                                              \
+    hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
                        grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records,     \
-                       grad_value, partials)
+                       grad_value, partials, cc)
     switch (C) {
-    case 16: if (rec12) BOXATTN_ACC_TR(16, true); else BOXATTN_ACC_TR(16, false); break;
-    case 32: if (rec12) BOXATTN_ACC_TR(32, true); else BOXATTN_ACC_TR(32, false); break;
-    case 64: if (rec12) BOXATTN_ACC_TR(64, true); else BOXATTN_ACC_TR(64, false); break;
+    case 16: BOXATTN_ACC_TR(16); break;
+    case 32: BOXATTN_ACC_TR(32); break;
+    case 64: BOXATTN_ACC_TR(64); break;
     }
 #undef BOXATTN_ACC_TR
 }
 
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                            const int4 *items, const int *n_items, const int *records, float *grad_value,
-                           float *partials, int wg_per_slice, int ns8, hipStream_t st)
+                           float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, hipStream_t st)
 {
     hipLaunchKernelGGL((binned_accumulate_f32_kernel<32>), dim3(wg_per_slice, ns8), dim3(64), 0, st, grad_out,
-                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials);
+                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc);
 }
 
 }  // namespace boxattn

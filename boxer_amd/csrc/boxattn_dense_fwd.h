@@ -32,7 +32,6 @@
 // LDS (the window buffer, after a barrier), added to the VALU sums and stored as one 16-byte piece per lane.
 #pragma once
 #include "boxattn_dense.h"
-#include "boxattn_scan_tail.h"     // ScanTail: the backward's block scans ride in front of this kernel's grid too
 
 namespace boxattn {
 
@@ -57,24 +56,24 @@ constexpr int kDenseZeroSlot = kDenseSlots - 1;        // a 64-byte row of zeros
 template <int L>
 __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
-    bf16_t *__restrict__ out, DensePlan pl, unsigned value_bytes, unsigned lead, ScanTail sct)
+    bf16_t *__restrict__ out, DensePlan pl, unsigned value_bytes, BinRide ride)
 {
-    // training forward: `lead` workgroups in front of the grid do the backward's block scans (fwd2_kernel does
-    // the same; boxattn_binned.h bin_scan_tail_body)
-    if (blockIdx.x < lead) {
-        if ((int)blockIdx.x < sct.plan.n_slices * kScanSub)
-            bin_scan_tail_body<256>(sct, (int)blockIdx.x / kScanSub, (int)blockIdx.x % kScanSub);
-        return;
-    }
     constexpr int C = 32, P = 4, LP = L * P;
     constexpr int kBias = 4096;                         // keeps the packed slot offset non-negative
     constexpr int kZeroOff = kDenseZeroSlot * kDenseSlotBytes;
     __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    // training forward: the backward's count pass and the scans chained behind it ride in this launch
+    // (boxattn_ride.h, bin_count_ride)
+    const RideRole role = ride_role(blockIdx.x, ride.grid);
+    if (role.rider) {
+        bin_count_ride<256>(ride, role.id, reinterpret_cast<int *>(win_lds));
+        return;
+    }
     DenseHot<L> hot;
     DenseMap Q;
     DenseWin wrow[L];
-    const DenseTileId t = dense_tile_of_block<L>(pl, blockIdx.x - lead, hot, Q, wrow);
+    const DenseTileId t = dense_tile_of_block<L>(pl, role.id, hot, Q, wrow);
     if (t.lq < 0) return;                                          // workgroup-uniform
     const int H = hot.H, h = t.h;
     // ---- lane -> (query of the wave's 4x4 sub-tile, lane of its quad)

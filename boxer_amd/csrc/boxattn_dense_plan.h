@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include "boxattn_combine.h"
 #include "boxattn_binplan.h"
+#include "boxattn_binpass.h"
 
 namespace boxattn {
 
@@ -60,56 +61,16 @@ inline unsigned dense_blocks(const DensePlan &p)
     return 8u * (unsigned)p.H * longest;
 }
 
-// The bin records of the destination-binned backward (boxattn_binned.h), counted and written by
-// these kernels' workgroups instead of the two bin_kernel passes: a workgroup's points are counted /
-// ranked in an LDS table over the slice's blocks and handed to the bins with ONE global atomic per
-// touched block -- `count`: += into counts[slice][block] (zeroed by the caller; bin_scan_kernel turns
-// them into `offsets` and leaves zeros behind), `fill`: cursor[slice][block] += n, returning the
-// workgroup's first slot.  Exact for any input; the record order inside a bin follows the atomics.
-// Every tile of a slice has points in the few blocks of the coarse levels: one counter per block would
-// take a slice's 238 workgroups (C2) one after the other -- same-address device atomics, measured
-// 17 us for the count pass alone.  So the workgroups are spread over kDenseGroups groups (tile index
-// mod 16) that play the part of the bin_kernel's workgroups: counts / first slots / cursors per
-// (slice, group, block), the scan kernels' two-level prefix over the groups as it is.
-constexpr int kDenseFillMaxBlocks = 1024;      // blocks per slice the LDS table is built for (4 per thread)
-constexpr int kDenseGroups = 16;
-constexpr int kDenseScanSub = 8;               // = kScanSub of boxattn_binned.h (sub-ranges of bin workgroups in the scan)
-struct DenseBinLevel { unsigned mw, mh; int blk0; };      // what blk_of() needs beyond the map size (BinLevel)
-struct DenseBin {
-    int nblk, rec_cap, lp_bits;    // BinPlan
-    DenseBinLevel lv[kDenseMaxLevels];
-    int *part;               // [slice][group][nblk]: count: += (zeroed by the caller); fill: first slot in the sub-range
-    const int *subtot;       // [slice][kScanSub][nblk] first slot of the group's sub-range in the bin (scan)
-    const int *offsets;      // [slice][nblk + 1] first record of every bin (scan)
-    int *cursor;             // [slice][group][nblk] zeros on entry (fill)
-    int *records;            // wide records {id, x, y, weight}, rec_cap per slice
-    int on;
-};
-inline DenseBin dense_bin(const BinPlan &bp, int *part, const int *subtot, const int *offsets, int *cursor,
-                          int *records)
-{
-    DenseBin b{};
-    b.nblk = bp.nblk; b.rec_cap = bp.rec_cap; b.lp_bits = bp.lp_bits;
-    for (int l = 0; l < kDenseMaxLevels && l < bp.L; ++l) b.lv[l] = DenseBinLevel{bp.lv[l].mw, bp.lv[l].mh, bp.lv[l].blk0};
-    b.part = part; b.subtot = subtot; b.offsets = offsets; b.cursor = cursor; b.records = records;
-    b.on = 1;
-    return b;
-}
-
-// bin.part[slice][group][block] += records of every block (zeroed by the caller)
-void launch_dense_count(const float *loc, const DensePlan &dp, const DenseBin &bin, hipStream_t st);
-
-// grad_loc / grad_attn of bf16 box attention on a query grid (+ the combine step's workers, if any;
-// + the bin records if bin.on)
+// grad_loc / grad_attn of bf16 box attention on a query grid (+ the backward's fill riders, if any:
+// ride.grid.n_riders > 0; the caller sets ride.grid.n_riders / .shift, the launcher places them: boxattn_ride.h)
 void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float *attn,
                             const uint16_t *grad_out, const DensePlan &dp, float *grad_loc,
-                            float *grad_attn, unsigned value_bytes, hipStream_t st,
-                            const CombineTail &tail, const DenseBin &bin);
+                            float *grad_attn, unsigned value_bytes, hipStream_t st, const BinRide &ride);
 
-// out of bf16 box attention on a query grid (boxattn_dense_fwd.h)
-struct ScanTail;             // boxattn_binned.h: the backward's block scans as extra workgroups (training forward), or null
+// out of bf16 box attention on a query grid (boxattn_dense_fwd.h) (+ the training forward's count riders
+// and the scans chained behind them, if any)
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, const ScanTail *scan_tail, hipStream_t st);
+                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride, hipStream_t st);
 
 // The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
 // because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per
@@ -117,11 +78,12 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
 constexpr size_t kAccTrMaxBytes = (size_t)1 << 31;
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
                           int H, int Lq, const int4 *items, const int *n_items, const int *records,
-                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, bool rec12, hipStream_t st);
+                          uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc,
+                          hipStream_t st);
 
 // float32 storage, C = 32: the accumulate on v_mfma_f32_32x32x2_f32 (boxattn_binned_tr.h); grad_out below 2 GB
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                            const int4 *items, const int *n_items, const int *records, float *grad_value,
-                           float *partials, int wg_per_slice, int ns8, hipStream_t st);
+                           float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, hipStream_t st);
 
 }  // namespace boxattn

@@ -29,6 +29,7 @@
 #include "boxattn_fast.h"
 #include "boxattn_grid.h"
 #include "boxattn_binned.h"
+#include "boxattn_binpass.h"
 
 namespace boxattn {
 
@@ -258,7 +259,6 @@ struct GatherIdx {
     // at the top of every wave) and `tiles per workgroup` was an emulated integer division there
     unsigned grid_x, grid_y;
     unsigned tps;         // point tiles per workgroup row: ceil(tiles / grid_y)
-    unsigned lead;        // workgroups in front of the kernel's own (fwd2_kernel: the scan workgroups)
 };
 
 // Which (query, head) pair a lane group works on.
@@ -268,11 +268,11 @@ struct GatherIdx {
 //                 b % 8 and PAIRS consecutive queries per wave: an XCD's L2 then only ever holds
 //                 the rows of ONE head (1/8 of `value`), however far apart the queries sample.
 template <int PAIRS>
-__device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, int H, int j, int wv,
+__device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, unsigned blk, int H, int j, int wv,
                                                  bool &active)
 {
+    // blk: the kernel's own workgroup index (riders taken out, boxattn_ride.h; index mod 8 = XCD as before)
     unsigned qh;
-    const unsigned blk = blockIdx.x - ix.lead;            // (lead: scan workgroups in front, a multiple of 8)
     if (ix.head_xcd) {
         const unsigned tile = (blk / 8) * kGatherWaves + wv;
         const unsigned bq = tile * PAIRS + j;
@@ -299,20 +299,17 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
-    GridSrc gs = GridSrc{}, ScanTail sct = ScanTail{})
+    GridSrc gs, BinRide ride)
 {
     static_assert(!(GRID && INST), "boxes -> grid is built for box attention");
     constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
-    if constexpr (!GRID) {
-        // the training forward: the backward's two scan kernels as one extra workgroup per slice
-        // (bin_scan_tail_body): they only need the count pass, which ran before this launch
-        // (they take the FIRST workgroup ids -- dispatched first, done long before the forward's last
-        // workgroup)
-        if (sct.n_wg > 0 && blockIdx.x < ix.lead) {
-            if ((int)blockIdx.x < sct.plan.n_slices * kScanSub)
-                bin_scan_tail_body<256>(sct, (int)blockIdx.x / kScanSub, (int)blockIdx.x % kScanSub);
-            return;
-        }
+    // the training forward: the backward's count pass and the scans chained behind it ride in this launch
+    // (boxattn_ride.h, bin_count_ride)
+    __shared__ int ride_lds[kRideLdsInts];
+    const RideRole role = ride_role(blockIdx.x, ride.grid);
+    if (role.rider) {
+        if (blockIdx.y == 0) bin_count_ride<256>(ride, role.id, ride_lds);
+        return;
     }
     typedef GeoTile<G, NH> Tile;
     typedef Row<ST, VEC> RowT;
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     u32x4_t *geo = geo_all[wv] + Tile::base(lane);   // this group's part of the tile
     bool active;
-    const unsigned qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
+    const unsigned qh = pair_of_lane<PAIRS>(ix, role.id, H, lane / G, wv, active);
     const int slot = lane % G;                      // step A: point slot; step B: channel chunk
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
@@ -569,19 +566,20 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
-    ScanTail sct = ScanTail{})
+    BinRide ride)
 {
     constexpr int C = VEC * G, NG = kWave / G;
     typedef Row<ST, VEC> RowT;
     constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;
     constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);
-    // the training forward: the backward's block scans as ix.lead extra workgroups in front (fwd2_kernel)
-    if (sct.n_wg > 0 && blockIdx.x < ix.lead) {
-        if ((int)blockIdx.x < sct.plan.n_slices * kScanSub)
-            bin_scan_tail_body<256>(sct, (int)blockIdx.x / kScanSub, (int)blockIdx.x % kScanSub);
+    // the training forward: the backward's count pass + scans ride in this launch (fwd2_kernel)
+    __shared__ int ride_lds[kRideLdsInts];
+    const RideRole role = ride_role(blockIdx.x, ride.grid);
+    if (role.rider) {
+        bin_count_ride<256>(ride, role.id, ride_lds);
         return;
     }
-    const unsigned blk = blockIdx.x - ix.lead;
+    const unsigned blk = role.id;
     __shared__ LevelTable lv;
     load_levels(lv, shapes, lsi, L);
 
@@ -700,22 +698,18 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const float *__restrict__ w_sp, const float *__restrict__ w_lv,
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask, int S, int H, int L,
     int Lq, int P, float *__restrict__ grad_loc, float *__restrict__ grad_sp,
-    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, GridSrc gs = GridSrc{},
-    CombineTail ct = CombineTail{})
+    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, GridSrc gs, BinRide ride)
 {
     static_assert(!GRID || (!INST && !WP && (G == 4 || G == 8)), "needs the buffered epilogue");
     constexpr int C = VEC * G, PAIRS = kWave / G;
-    if (ct.workers > 0 && blockIdx.x >= ix.grid_x) {          // the appended combine workgroups
-        if (blockIdx.y == 0) {
-            const int w = (int)((blockIdx.x - ix.grid_x) * kGatherWaves + threadIdx.x / kWave);
-            const int s = w / ct.workers;
-            if (s < ct.plan.n_slices)
-                combine_partials_body<ST, C>(ct.combos, ct.n_items, ct.partials, ct.plan, S, H,
-                                             static_cast<ST *>(ct.grad_value), s, w % ct.workers,
-                                             ct.workers, (int)(threadIdx.x & (kWave - 1)));
-        }
+    // the backward's fill pass rides in this launch (boxattn_ride.h, bin_fill_ride)
+    __shared__ int ride_lds[kRideLdsInts];
+    const RideRole role = ride_role(blockIdx.x, ride.grid);
+    if (role.rider) {
+        if (blockIdx.y == 0) bin_fill_ride<256>(ride, role.id, ride_lds);
         return;
     }
+    const unsigned blk = role.id;
     typedef GeoTile<G, 1> Tile;                      // offsets only: the weights stay with lane t
     typedef Row<ST, VEC> RowT;
     constexpr int PSB = RowGeom<ST, VEC, G>::kPieceStride;    // bytes between a lane's pieces
@@ -748,13 +742,13 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     bool active;
     unsigned qh;
     if constexpr (WP) {
-        qh = blockIdx.x * kGatherWaves + wv;                      // one pair per wave
+        qh = blk * kGatherWaves + wv;                             // one pair per wave
         if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
-            qh = ((blockIdx.x / 8) * kGatherWaves + wv) * (unsigned)H + blockIdx.x % 8;
+            qh = ((blk / 8) * kGatherWaves + wv) * (unsigned)H + blk % 8;
         active = qh < ix.n_qh;
         qh = active ? qh : ix.n_qh - 1;
     } else {
-        qh = pair_of_lane<PAIRS>(ix, H, lane / G, wv, active);
+        qh = pair_of_lane<PAIRS>(ix, blk, H, lane / G, wv, active);
     }
     const int slot = lane % G;
     if constexpr (BOXATTN_TUNE_PG_TRACE == 2) {

@@ -19,12 +19,13 @@ from torch.autograd.function import once_differentiable
 from . import ops
 
 
-# Whether the Functions' forward already prepares the backward's plan (the binning of the sample
-# points) in a scratch tensor that then lives until the matching backward.  Everything runs on one
-# stream, so the step takes the same time either way; a held plan costs its workspace per layer
-# (boxattn_bwd_workspace_bytes: 0.3 GB at BoxeR-R50 COCO shapes in bf16, 3.6 GB over 6 + 6 layers),
-# a backward that plans for itself only needs one transient workspace.  Default: off.
-PLAN_IN_FORWARD = False
+# Whether the Functions' forward already prepares the backward's plan: the count pass and the scans of
+# the destination-binned backward ride in the forward kernel's launch (ops.*_forward_train) and leave a
+# small plan buffer (boxattn_plan_bytes: 1.4 MB at BoxeR-R50 encoder shapes) that lives until the matching
+# backward; the backward then starts with the point-gradient kernel (fill pass riding along) instead of
+# with three launches of binning.  On by default: this is the path bench.py times.  Off: the backward
+# plans for itself (same results).
+PLAN_IN_FORWARD = True
 
 
 def set_plan_in_forward(flag):
@@ -268,7 +269,10 @@ class BoxAttnFromBoxesFunction(Function):
                 angle_mode, attention_weights, native_bf16):
         # no cast_inputs: under autocast a bf16 value (ValueMaskCastFunction's output) would be
         # widened to float32 by the decorator and narrowed again here -- two passes over B*S*d.
-        # custom_fwd still disables autocast inside; the geometry / weights go to float32 by hand
+        # (Without cast_inputs custom_fwd leaves the caller's autocast state ON inside forward and
+        # custom_bwd restores it in backward: harmless here because every operation of both bodies is
+        # a C-ABI call or an explicit cast -- keep it that way, or wrap new torch math in
+        # torch.autocast("cuda", enabled=False).)
         ctx.value_dtype = value.dtype                # the caller's type: grad_value goes back in it
         if native_bf16:
             value = value if value.dtype == torch.bfloat16 else value.to(torch.bfloat16)

@@ -88,17 +88,14 @@ def _host_table(t):
 
 
 class BackwardPlan:
-    """Opaque hand-over from a training forward to the matching backward: the scratch tensor in
-    which the forward already binned the sample points (the binning only depends on the sampling
-    locations and -- bf16 box attention, whose records carry them -- the attention weights),
-    plus what it is valid for."""
+    """Opaque hand-over from a training forward to the matching backward: the (small) device buffer in
+    which the forward's launch already counted and scanned the sample points' destination bins (the
+    binning only depends on the sampling locations), plus what it is valid for."""
 
-    __slots__ = ("ws", "key", "kind")
+    __slots__ = ("buf", "key")
 
-    def __init__(self, ws, key, kind=1):
-        # kind: 1 = binning plan, 2 = query-grid tile boxes, 3 = counted bins whose records the
-        # backward writes, 4 = binning plan with 12-byte records (what *_fwd_train_* reported)
-        self.ws, self.key, self.kind = ws, key, kind
+    def __init__(self, buf, key):
+        self.buf, self.key = buf, key
 
 
 def _plan_key(dims, loc, weights):
@@ -106,45 +103,71 @@ def _plan_key(dims, loc, weights):
                                                     for t in (loc,) + tuple(weights))
 
 
-def _workspace(value, shapes, lsi, dims):
-    lib = _lib.load()
+def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
+    """A scratch tensor of the size the library asks for (query: boxattn_plan_bytes /
+    boxattn_bwd_workspace_bytes; None for 0 bytes when minimum is 0) + the host level tables."""
     sh, ls = _host_table(shapes), _host_table(lsi)
     is_bf16 = int(value.dtype == torch.bfloat16)
-    nbytes = lib.boxattn_bwd_workspace_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)
-    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=value.device)
-    return ws, sh, ls
+    nbytes = max(int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)), minimum)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
+    return buf, sh, ls
+
+
+_STATE = {}          # (device index, stream handle) -> zeroed ticket buffer the library keeps zero
+
+
+def _state_buffer(device, stream, nbytes):
+    """The riders' ticket buffer (include/boxattn.h, *_fwd_train_*: `state`): zeroed once, one per stream --
+    calls on one stream never overlap and every call leaves it zero -- instead of a zero-fill launch in
+    front of every training forward."""
+    key = (device.index, stream)
+    buf = _STATE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+        _STATE[key] = buf
+    return buf
 
 
 def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     """*_fwd_train_*: forward + (when the binned backward applies) the backward's plan."""
     import ctypes
     lib = _lib.load()
-    ws, sh, ls = _workspace(value, shapes, lsi, dims)
+    buf, sh, ls = _sized_buffer(lib.boxattn_plan_bytes, value, shapes, lsi, dims, minimum=0)
     built = ctypes.c_int(0)
+    fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream(value.device).cuda_stream
+        state = _state_buffer(value.device, stream, lib.boxattn_state_bytes(dims[0], dims[2]))
+        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
+                sh.ctypes.data, ls.ctypes.data, buf.data_ptr() if buf is not None else 0,
+                buf.numel() if buf is not None else 0, state.data_ptr(), state.numel(),
+                ctypes.addressof(built), stream)
+    if rc != 0:
+        _STATE.pop((value.device.index, stream), None)      # (its tickets may not be zero any more)
+        raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
+    return BackwardPlan(buf, _plan_key(dims, loc, weights)) if built.value else None
+
+
+def workspace_bytes(value, shapes, lsi, dims):
+    """(plan bytes, backward workspace bytes) the library asks for at these dimensions."""
+    lib = _lib.load()
+    sh, ls = _host_table(shapes), _host_table(lsi)
+    is_bf16 = int(value.dtype == torch.bfloat16)
+    return (int(lib.boxattn_plan_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)),
+            int(lib.boxattn_bwd_workspace_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)))
+
+
+def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
+    """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch (+ plan)."""
+    lib = _lib.load()
+    ready = plan is not None and plan.key == _plan_key(dims, loc, weights)
+    ws, sh, ls = _sized_buffer(lib.boxattn_bwd_workspace_bytes, value, shapes, lsi, dims)
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(),
-                ctypes.addressof(built), stream)
-    if rc != 0:
-        raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
-    return BackwardPlan(ws, _plan_key(dims, loc, weights), built.value) if built.value else None
-
-
-def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
-    """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch."""
-    lib = _lib.load()
-    ready = plan.kind if (plan is not None and plan.key == _plan_key(dims, loc, weights)) else 0
-    if ready:
-        ws, sh, ls = plan.ws, _host_table(shapes), _host_table(lsi)
-    else:
-        ws, sh, ls = _workspace(value, shapes, lsi, dims)
-    fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream(value.device).cuda_stream
-        rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
-                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(), ready, stream)
+                plan.buf.data_ptr() if ready else 0, plan.buf.numel() if ready else 0, stream)
     if rc != 0:
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
 
@@ -178,8 +201,8 @@ def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, att
 def box_attn_forward_train(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                            im2col_step):
     """Forward for training: -> (output, plan).  ``plan`` (or None) goes to
-    ``box_attn_backward(..., plan=plan)``: the forward already binned the sample points for the
-    backward, concurrently with the forward kernel.  Not part of the reference API."""
+    ``box_attn_backward(..., plan=plan)``: the forward's launch already counted and scanned the
+    destination bins of the sample points for the backward.  Not part of the reference API."""
     dims, loc, (attn,), _ = _prepare(value, spatial_shapes, level_start_index, sampling_loc,
                                      [attn_weight])
     B, S, H, C, L, Lq, P = dims
@@ -441,7 +464,8 @@ def box_attn_backward_to_boxes(value, spatial_shapes, level_start_index, grid, a
                                        [attn_weight], [("grad_output", grad_output)])
     if value.dtype not in (torch.float32, torch.bfloat16) or loc.dtype != torch.float32:
         return None
-    ws, sh, ls = _workspace(value, spatial_shapes, level_start_index, dims)
+    ws, sh, ls = _sized_buffer(_lib.load().boxattn_bwd_workspace_bytes, value, spatial_shapes,
+                               level_start_index, dims)
     grad_value = torch.empty_like(value)
     grad_offsets = torch.empty_like(offsets)
     grad_rows = torch.empty((B, Lq, H, L, 5), dtype=torch.float32, device=value.device) \

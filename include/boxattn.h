@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 6
+#define BOXATTN_ABI_VERSION 7
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -66,8 +66,9 @@ int boxattn_fwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_t
 
 /* Forward with HOST copies of the two level tables next to the device ones (either may be
  * NULL): lets the library recognise the encoder case -- one query per pixel of the packed
- * multi-level map (Lq == S; box_transformer.py:346-354) -- and run the query-grid kernels
- * (LDS-staged value windows) instead of the row gathers.  Same results as boxattn_fwd_*. */
+ * multi-level map (Lq == S; box_transformer.py:346-354) -- and run the window-staged kernels
+ * (a query tile's value windows in LDS, arithmetic on the matrix cores) instead of the row
+ * gathers.  Same results as boxattn_fwd_*. */
 int boxattn_fwd_hl_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *attn, int B, int S, int H, int C, int L,
                        int Lq, int P, float *out, const int64_t *shapes_host,
@@ -133,21 +134,17 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  *       device->host sync.  May be NULL: the call then behaves like the plain backward.
  *   workspace / workspace_bytes : device scratch, 256-byte aligned, contents ignored and
  *       clobbered; size from boxattn_bwd_workspace_bytes() (covers the bf16 fp32 scratch too).
+ *       It only lives inside the call (bin records, partial tiles).
+ *   plan / plan_bytes : NULL / 0 -- the call plans for itself (count + scan passes first) -- or the
+ *       buffer a *_fwd_train_* call filled (*plan_built == 1) for the SAME sampling locations,
+ *       dimensions and option settings; it is only read.
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
- * B*S*H*C floats).  Only float32 and bfloat16 exist here; float64 uses the plain backward.
- * plan_ready: 0 = the call prepares everything itself; otherwise the value a *_fwd_train_* call
- * returned in *plan_built for the SAME sampling locations and dimensions -- 1: `workspace` holds
- * the binning plan, 2: it holds the query-grid tile boxes (bf16 box attention in the encoder
- * case, Lq == S: no global binning at all), 3: it holds the counted and
- * scanned bins whose records the backward's point-gradient kernel writes itself (bf16 box attention
- * in the encoder case, window-staged kernels), 4: like 1 with 12-byte bin records
- * (bf16 box attention).  A plan the backward cannot use
- * (operands the fast paths reject) is ignored and the call falls back.
- * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`; with
- * boxattn_set_variant(6) the point-gradient kernel runs on a library-owned low-priority helper
- * stream (one per device, created on first use) that is forked from and joined back into
- * `stream` with events, so the caller still sees one in-order stream (valid under capture).
+ * B*S*H*C floats); a plan the backward cannot use (operands the fast paths reject) is ignored.
+ * Only float32 and bfloat16 exist here; float64 uses the plain backward.
+ * The binned path uses no float atomics and no zero-fill.  Everything runs on `stream`:
+ *   [count + scans, unless a plan is given] -> point-gradient kernel with the fill pass riding in its
+ *   launch -> accumulate kernel (the partial tiles of chunked blocks summed by their last chunk).
  */
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                                    const int64_t *shapes_host, const int64_t *lsi_host);
@@ -155,28 +152,28 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        const float *loc, const float *attn, const float *grad_out, int B, int S,
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
-                       void *workspace, size_t workspace_bytes, int plan_ready,
-        void *stream);
+                       void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes,
+                       void *stream);
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
-                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
-        void *stream);
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        const void *plan, size_t plan_bytes, void *stream);
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
                         const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
-                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
-        void *stream);
+                        const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                        const void *plan, size_t plan_bytes, void *stream);
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
                          const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
-                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes, int plan_ready,
-        void *stream);
+                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
+                         const void *plan, size_t plan_bytes, void *stream);
 
 /*
  * ---- reference windows + box offsets -> sampling grid (opt-in; SURVEY.md 8(f) N1, first step) --
@@ -208,54 +205,50 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
 
 /*
  * ---- training forward: forward + backward plan ----------------------------------------------
- * Same as the plain forward, and additionally (when the binned backward applies) runs the
- * binning passes of the backward -- they only depend on the sampling locations and, for the
- * bf16 box flavour, whose 16-byte records carry them, the attention weights -- ahead of the
- * forward kernel (variant 6: on the library's helper stream, next to it) into `workspace`
- * (boxattn_bwd_workspace_bytes bytes; it must stay untouched until the matching *_bwd_ws_*
- * call, which is then given plan_ready = *plan_built).  *plan_built is set to the kind of plan
- * that was built (1, 2 or 3, see above), 0 if the call was just a plain forward (shape not eligible /
- * workspace too small).
+ * Same as the plain forward, and additionally (when the binned backward applies) the count pass and
+ * the scans of the backward -- they only depend on the sampling locations -- ride in the forward
+ * kernel's launch as extra workgroups and leave the backward's PLAN in `plan` (boxattn_plan_bytes()
+ * bytes, 256-byte aligned, contents ignored on entry: per bin workgroup and block the first record
+ * slot, the work-item list; 1.4 MB at BoxeR-R50 encoder shapes).  It must stay untouched until the
+ * matching *_bwd_ws_* call.  *plan_built is 1 if a plan was built, 0 if the call was just a plain
+ * forward (shape not eligible / buffer too small / NULL).
+ * state / state_bytes: NULL / 0, or a device buffer of boxattn_state_bytes(B, H) bytes (4-byte aligned) that
+ * the caller ZEROED ONCE and keeps for the calls it issues on THIS stream: the riders' hand-off tickets.
+ * Every call leaves it zero again, and calls on one stream never overlap, so it is never cleared again.
+ * Without it the tickets live in `plan` and a zero-fill launch (~5 us) precedes the forward kernel.
  */
+size_t boxattn_state_bytes(int B, int H);
+size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
+                          const int64_t *shapes_host, const int64_t *lsi_host);
 int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                           const float *loc, const float *attn, int B, int S, int H, int C, int L,
                           int Lq, int P, float *out, const int64_t *shapes_host,
-                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                          int *plan_built, void *stream);
+                          const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
+                          size_t state_bytes, int *plan_built, void *stream);
 int boxattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *attn, int B, int S, int H, int C, int L,
                            int Lq, int P, uint16_t *out, const int64_t *shapes_host,
-                           const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                           int *plan_built, void *stream);
+                           const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
+                           size_t state_bytes, int *plan_built, void *stream);
 int instattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *spatial_w, const float *level_w, int B,
                            int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
-                           const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                           size_t workspace_bytes, int *plan_built, void *stream);
+                           const int64_t *shapes_host, const int64_t *lsi_host, void *plan,
+                           size_t plan_bytes, void *state, size_t state_bytes, int *plan_built,
+                           void *stream);
 int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                             const float *loc, const float *spatial_w, const float *level_w, int B,
                             int S, int H, int C, int L, int Lq, int P, uint16_t *out,
                             uint16_t *mask_out, const int64_t *shapes_host,
-                            const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                            int *plan_built, void *stream);
+                            const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
+                            size_t state_bytes, int *plan_built, void *stream);
 
 /*
  * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):
  *   0 = automatic choice (default), 1 = force the generic kernels (any C),
  *   2 = first-generation fast kernels with fp atomics (error if the shape does not qualify;
  *       never the binned backward),
- *   3 = binned backward required (error if not eligible),
- *   4 = like 0 but everything runs on the caller's stream (no helper stream),
- *   5 = like 0 but the instance forward with few (query, head) pairs keeps the workgroup
- *       split of the points instead of the one-wave-per-pair kernel.
- *   6 = like 0 but the helper stream is used (point gradients next to binning / accumulate,
- *       binning next to the training forward).  0 behaves like 4: measured faster for both
- *       storage types.
- *   7 = like 0 without the query-grid forward kernel (row gathers also in the encoder case),
- *   8 = like 0 without the query-grid backward (the binned backward also in the encoder case),
- *  11 = like 0 but float32 box attention (32 channels per head) accumulates grad_value on the
- *       matrix cores (two-term bf16 split of the upstream rows, ~2e-5 relative per term) instead
- *       of the float32-exact VALU kernel (measured: no gain).
+ *   3 = like 0, but an error if the binned backward is not eligible.
  * Returns the previous value.
  */
 int boxattn_set_variant(int variant);
@@ -328,47 +321,33 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
 
 /*
  * Tuning options for A/B runs (process-wide, relaxed atomics; 0 = default).  Returns the
- * previous value, -1 for an unknown key.
- *   0  query-grid kernels, queries per tile: 1 = 16 x 8, 2 = 8 x 8
- *   1  query-grid kernels, LDS rows per workgroup for the value windows
- *   2  query-grid kernels, cap of the data-driven window margin (pixels)
- *   3  query-grid kernels, fixed window margin in 1/16 query-level pixels (0 = data-driven)
- *   4  query-grid kernels, timing ablations (wrong results): 1 no compute, 2 no staging
- *   5  query-grid backward: target records per work item (default 512)
- *   6  query-grid forward: 1 = use the LDS-tiled forward kernel (default off: measured slower)
- *   7  query-grid backward, timing ablations (wrong results): 1 no rounds, 2 no candidates, 4 no scan
- *   8  query-grid backward: persistent waves per XCD (default 384)
- *   9  query-grid backward: 1 = use it for bf16 box attention with Lq == S (default off: measured
- *      slower than the binned backward)
+ * previous value, -1 for an unknown key.  (The key numbers of earlier ABI versions are kept; the keys
+ * of kernels that were removed are gone.)
  *  10  binned backward: records per work item (multiple of 64; default: from the number of sample
- *      points, 128 ... 1024).  Set it before boxattn_bwd_workspace_bytes: the workspace layout
- *      depends on it.
+ *      points, 128 ... 1024).  Set it before boxattn_plan_bytes / boxattn_bwd_workspace_bytes: the
+ *      layouts depend on it.
  *  11  window-staged point-gradient kernel of the encoder case (bf16 box attention, Lq == S, C = 32,
  *      2x2 points, <= 4 levels): 0 library default (on), 1 off (row-gather kernel), 2 on
  *  12  ... margin of its staged windows for the predicted box offsets, in tenths of a quarter of the
  *      expected box (0 = default 25); 13 ... expected box size in pixels of the query's own level
  *      (0 = default 4, BoxeR's reference windows).  Placement only: results do not depend on them.
- *  14  ... the window-staged kernels also count and write the bin records (no bin_kernel passes):
- *      0 / 1 off (default: measured no faster), 2 on.  Set before *_fwd_train_* / the backward.
- *  15  training forward: the backward's two scan kernels ride in the forward kernel's launch:
- *      0 default (on), 1 off (stand-alone bin_scan_a_kernel / bin_scan_kernel)
- *  16  matrix-core accumulate of bf16 box attention: 0 default (binned_accumulate_tr_kernel: rows read
- *      with the transposing LDS read), 1 the round-1/2 kernel (binned_accumulate_mfma_kernel)
- *  18  12-byte bin records for bf16 box attention (footprint corner relative to the block + 16-bit fractions
- *      instead of float32 coordinates): 0 / 1 off (default), 2 on -- 2 % faster, but a weight is then exact to
- *      2^-17 ABSOLUTE instead of relative.  Set before *_fwd_train_* / the backward.
- *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands
- *      and accumulation, wide records): 0 / 1 off (default: measured slower on model-like inputs), 2 on.
- *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
+ *  15  riders: the count pass + scans inside the training forward's launch, the fill pass
+ *      inside the point-gradient launch, chunked blocks summed inside the accumulate launch:
+ *      0 default (on), 1 off (launches of their own)
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
+ *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands
+ *      and accumulation, 16-byte records): 0 / 1 off (default), 2 on.
+ *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
+ *  20  where the riders sit in their host kernel's grid: (s_count + 1) | (s_fill + 1) << 4 -- a group of 8
+ *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | (d + 1) << 8: 1024 >> d bin
+ *      workgroups (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
  */
 int boxattn_set_option(int key, int value);
 
 /*
- * Debugging aid of the window-staged kernels: builds with -DBOXATTN_DENSE_DEBUG=1/2 write per-point
- * corner sums / per-wave time stamps to this device buffer (tools/gpu_dense_debug.py,
- * tools/gpu_dense_trace.py).  Ignored by regular builds.
+ * Debugging aid of the window-staged kernels: builds with -DBOXATTN_DENSE_DEBUG=2 write per-wave time
+ * stamps to this device buffer (tools/gpu_dense_trace.py).  Ignored by regular builds.
  */
 void boxattn_set_debug_buffer(float *device_buffer);
 
@@ -376,13 +355,13 @@ void boxattn_set_debug_buffer(float *device_buffer);
  * Kernel timing for benchmarks (process-global, not thread-safe).  Between _begin and _end the
  * library brackets the launches of its main kernels with hipEvents recorded on the launch
  * stream, in BOXATTN_PROFILE_SLOTS slots:
- *   0  forward sampling kernel
- *   1  backward, point gradients (grad_loc / grad_weight) -- or the whole atomic backward
- *      kernel when the binned algorithm is not used
- *   2  backward, grad_value accumulate kernel
- *   3  backward, binning passes (count + scan + fill) of the binned algorithm
- *   4  backward, combine pass over the partial tiles of split blocks
- *   5  backward, preparation pass of the query-grid algorithm (tile bounding boxes)
+ *   0  forward sampling kernel (training forward: + the count / scan riders of its launch)
+ *   1  backward, point gradients (grad_loc / grad_weight; + the fill riders of its launch) -- or the
+ *      whole atomic backward kernel when the binned algorithm is not used
+ *   2  backward, grad_value accumulate kernel (+ the in-launch combine of chunked blocks)
+ *   3  backward, binning passes run as launches of their own (count / scan / fill)
+ *   4  backward, combine pass over the partial tiles of split blocks as a launch of its own
+ *   5  unused
  * Zero-fills and the bf16 conversion pass are not included.  _end synchronises the events and
  * writes, per slot, the summed duration in milliseconds and the number of launches into the two
  * BOXATTN_PROFILE_SLOTS-element arrays.  At most 4096 launches per slot are kept.

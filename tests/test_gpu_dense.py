@@ -16,7 +16,7 @@ import bench
 pytestmark = pytest.mark.gpu
 
 OPT_DENSE = 11          # boxattn_set_option key: 0 library default, 1 dense kernels off, 2 on
-OPT_DENSE_FILL = 14     # ... the window-staged kernels also count and write the bin records: 2 on (default off)
+OPT_RIDERS = 15         # count / scan / fill / combine inside the forward, point-gradient, accumulate launches: 0 on, 1 off
 OPT_DENSE_FWD = 17      # window-staged matrix-core forward: 0 library default (on), 1 off (fwd2_kernel), 2 on
 
 
@@ -44,14 +44,14 @@ def forward_kernel(request):
     lib.boxattn_set_option(OPT_DENSE_FWD, old)
 
 
-@pytest.fixture(params=[False, True], ids=["bin_kernel", "own_binning"])
+@pytest.fixture(params=[0, 1], ids=["riders", "own_launches"])
 def binning(request):
-    """Both ways of binning under the window-staged point gradients: the two bin_kernel passes (default)
-    and count / records by the window-staged kernels themselves (atomic cursors per block and group)."""
+    """Both ways of running the backward's overhead passes: as riders inside the forward / point-gradient /
+    accumulate launches (default) and as launches of their own."""
     lib = _lib()
-    old = lib.boxattn_set_option(OPT_DENSE_FILL, 2 if request.param else 0)
+    old = lib.boxattn_set_option(OPT_RIDERS, request.param)
     yield request.param
-    lib.boxattn_set_option(OPT_DENSE_FILL, old)
+    lib.boxattn_set_option(OPT_RIDERS, old)
 
 
 def make_case(levels, family, H=8, B=2, seed=0):
@@ -211,16 +211,28 @@ def test_staged_forward_ignores_value_where_no_point_counts():
     assert torch.equal(out[:, 5], torch.zeros_like(out[:, 5]))
 
 
-OPT_SCAN_TAIL = 15      # 0 default (the block scans ride in the forward kernel's launch), 1 off
+@pytest.mark.parametrize("shift", [0, 1, 3], ids=["in_front", "every_2nd", "every_8th"])
+def test_rider_placement_does_not_change_results(shift, dense_switch):
+    """Where the rider groups sit in their host kernel's grid (boxattn_set_option(20)) is a speed matter only."""
+    lib = _lib()
+    dense_switch(True)
+    inp = make_case(LEVELS["4lv_odd"], "mixed", seed=11)
+    old = lib.boxattn_set_option(20, (shift + 1) | ((shift + 1) << 4))
+    try:
+        out, grads = run(inp)
+    finally:
+        lib.boxattn_set_option(20, old)
+    for name, worst, tol in bench.parity_report(inp, out, grads):
+        assert worst <= tol, (shift, name, worst)
 
 
 @pytest.mark.parametrize("fwd", [2, 1], ids=["staged_fwd", "gather_fwd"])
-def test_scans_inside_the_forward_launch_match_the_scan_kernels(fwd):
-    """The training forward runs the backward's two scan kernels as extra workgroups of the forward
-    kernel (bin_scan_tail_body: a ticket per slice, the last workgroup scans the blocks).  Same plan as
-    the stand-alone kernels -- compared through what the backward makes of it -- for both storage
-    types, and stable over many back-to-back steps (an inter-workgroup hand-off that goes stale shows
-    up as a wrong bin offset sooner or later)."""
+def test_riders_match_the_stand_alone_passes(fwd):
+    """The training step with the count pass + scans riding in the forward kernel's launch, the fill pass
+    in the point-gradient kernel's and the chunked blocks combined inside the accumulate launch, against
+    the same passes as launches of their own: same plan -- compared through what the backward makes of it
+    -- for both storage types, and stable over many back-to-back steps (an inter-workgroup hand-off that
+    goes stale shows up as a wrong bin offset or a missing partial tile sooner or later)."""
     from boxer_amd import ops
     lib = _lib()
     old_fwd = lib.boxattn_set_option(OPT_DENSE_FWD, fwd)
@@ -229,7 +241,7 @@ def test_scans_inside_the_forward_launch_match_the_scan_kernels(fwd):
         v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
         res = {}
         for mode in (1, 0):
-            old = lib.boxattn_set_option(OPT_SCAN_TAIL, mode)
+            old = lib.boxattn_set_option(OPT_RIDERS, mode)
             try:
                 outs = []
                 for it in range(60 if mode == 0 else 2):
@@ -239,7 +251,7 @@ def test_scans_inside_the_forward_launch_match_the_scan_kernels(fwd):
                 torch.cuda.synchronize()
                 res[mode] = outs
             finally:
-                lib.boxattn_set_option(OPT_SCAN_TAIL, old)
+                lib.boxattn_set_option(OPT_RIDERS, old)
         ref = res[1][0]
         for out, gv, gl, ga in res[0]:
             assert torch.equal(out, ref[0]) and torch.equal(gl, ref[2]) and torch.equal(ga, ref[3])

@@ -19,7 +19,7 @@ from oracle import boxattn_oracle as oc
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 1e-2}
-VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3, "split": 5, "binned_mfma32": 11}
+VARIANTS = {"auto": 0, "generic": 1, "atomic": 2, "binned": 3}
 
 
 def dev(a, dtype=None):
@@ -93,7 +93,7 @@ def test_box_golden(name, dtype, variant):
     close(ga, g["grad_attn"], dtype, "grad_attn")
 
 
-@pytest.mark.parametrize("variant", ["auto", "generic", "split"])
+@pytest.mark.parametrize("variant", ["auto", "generic"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("name", golden_io.INST)
 def test_instance_golden(name, dtype, variant):
@@ -224,7 +224,7 @@ FAST_CFGS = [SEEDED[0], SEEDED[1], SEEDED[2], SEEDED[3],
              ([(16, 24)], 1, 8, 32, 3000, 4)]                              # chunked heavy bins
 
 
-@pytest.mark.parametrize("variant", ["atomic", "binned", "binned_mfma32"])
+@pytest.mark.parametrize("variant", ["atomic", "binned"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", FAST_CFGS, ids=[str(i) for i in range(len(FAST_CFGS))])
 def test_box_backward_algorithms(cfg, dtype, variant):
@@ -266,64 +266,6 @@ def test_float32_matrix_core_accumulate(cfg, with_plan):
         res[mode] = gv
         close(gv, want[0], torch.float32, "grad_value (float32 accumulate %d)" % mode)
     assert (res[2] - res[1]).abs().max().item() <= 1e-5 * max(1.0, res[1].abs().max().item())
-
-
-OPT_REC12 = 18          # boxattn_set_option: 2 = 12-byte bin records for bf16 box attention (opt-in), 0 / 1 = 16-byte records
-
-
-@pytest.mark.parametrize("with_plan", [False, True], ids=["own_binning", "forward_plan"])
-@pytest.mark.parametrize("cfg", FAST_CFGS + [SEEDED[6], SEEDED[7]], ids=[str(i) for i in range(len(FAST_CFGS) + 2)])
-def test_both_bin_record_formats(cfg, with_plan):
-    """bf16 grad_value through 12-byte records (footprint corner relative to the destination block, 16-bit
-    fractions) and through 16-byte records (float32 coordinates): both against the oracle and against each
-    other to 2^-16 of a weight; with the backward's own binning and with a training forward's plan."""
-    from boxer_amd import _lib, ops
-    g = _seeded(*cfg, seed=29, lo=-0.2, hi=1.2)
-    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])
-    value, loc, attn = dev(g["value"], torch.bfloat16), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
-    shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], torch.bfloat16)
-    res = {}
-    for mode in (2, 1):
-        old = _lib.load().boxattn_set_option(OPT_REC12, mode)
-        try:
-            if with_plan:
-                _, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
-                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)[0]
-            else:
-                gv = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64)[0]
-            torch.cuda.synchronize()
-        finally:
-            _lib.load().boxattn_set_option(OPT_REC12, old)
-        res[mode] = gv
-        close(gv, want[0], torch.bfloat16, "grad_value (records %d)" % mode)
-    a, b = res[2].float(), res[1].float()
-    assert (a - b).abs().max().item() <= 2.0 ** -7 * max(1.0, b.abs().max().item())
-
-
-OPT_ACC_TR = 16         # boxattn_set_option: 0 binned_accumulate_tr_kernel (default), 1 binned_accumulate_mfma_kernel
-
-
-@pytest.mark.parametrize("cfg", FAST_CFGS + [SEEDED[7]], ids=[str(i) for i in range(len(FAST_CFGS) + 1)])
-def test_both_matrix_core_accumulate_kernels(cfg):
-    """bf16 grad_value from the two accumulate kernels (rows read with the transposing LDS read /
-    rows transposed in registers; C = 16, 32, 64): both against the oracle, and against each other
-    to float32 rounding of the weights (the order of the products inside a weight differs)."""
-    from boxer_amd import _lib
-    g = _seeded(*cfg, seed=23, lo=-0.2, hi=1.2)
-    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
-                                g["grad_out"])
-    res = {}
-    for mode in (0, 1):
-        old = _lib.load().boxattn_set_option(OPT_ACC_TR, mode)
-        try:
-            res[mode] = run_box(g, torch.bfloat16, "binned")[1]
-        finally:
-            _lib.load().boxattn_set_option(OPT_ACC_TR, old)
-        close(res[mode], want[0], torch.bfloat16, "grad_value (accumulate kernel %d)" % mode)
-    a, b = res[0].float(), res[1].float()
-    scale = max(1.0, b.abs().max().item())
-    # (one bf16 ulp where a sum lands on a rounding boundary)
-    assert (a - b).abs().max().item() <= 2.0 ** -7 * scale
 
 
 @pytest.mark.parametrize("variant", ["atomic", "binned"])
@@ -861,9 +803,10 @@ def test_bf16_accumulate_single_terms_are_correctly_rounded(C):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_forward_plan(dtype):
-    """box_attn_forward_train bins the sample points for the backward while the forward kernel
-    runs; the backward that receives the plan must give the same gradients, and a plan that no
-    longer matches the locations (in-place update) must be ignored, not trusted."""
+    """box_attn_forward_train counts and scans the sample points' destination bins for the backward
+    inside the forward kernel's launch; the backward that receives the plan must give the same
+    gradients, and a plan that no longer matches the locations (in-place update) must be ignored,
+    not trusted."""
     from boxer_amd import ops
     g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=41, lo=-0.2, hi=1.2)
     cdt = _cdt(dtype)
@@ -899,7 +842,7 @@ def test_training_forward_plan(dtype):
 @pytest.mark.parametrize("plan_in_forward", [False, True])
 def test_functions_use_the_plan_and_match(plan_in_forward):
     """The autograd Functions with and without the forward preparing the backward's plan
-    (functions.PLAN_IN_FORWARD; off by default: the workspace is then transient)."""
+    (functions.PLAN_IN_FORWARD, on by default)."""
     from boxer_amd import BoxAttnFunction, InstanceAttnFunction, functions
     old = functions.set_plan_in_forward(plan_in_forward)
     try:
@@ -935,114 +878,6 @@ def _functions_match():
                                    g["level_w"], g["grad_out"], g["grad_mask"])
     close(v.grad, wi[0], torch.float32, "instance grad_value")
     close(sw.grad, wi[2].reshape(sw.shape), torch.float32, "instance grad_spatial")
-
-
-# ------------------------------------------------------------------ query-grid (encoder) kernels
-def _grid_inputs(levels, dtype, family, batch=2, seed=0):
-    """Encoder-shaped inputs (one query per pixel) from bench.make_inputs on a custom map."""
-    import bench
-    bench.WORKLOADS["_T"] = (levels, "S", 4, "box")
-    try:
-        return bench.make_inputs("_T", dtype, "cuda", family=family, batch=batch, seed=seed)
-    finally:
-        del bench.WORKLOADS["_T"]
-
-
-GRID_LEVELS = [
-    [(37, 53), (19, 27), (10, 14), (5, 7)],        # 4 levels, ragged tiles on every level
-    [(64, 48), (32, 24)],                          # 2 levels (the BEV encoder's geometry)
-    [(16, 16), (8, 8), (4, 4), (1, 3)],            # whole levels inside one tile, a 1-row level
-]
-
-
-@pytest.mark.parametrize("shape_opt", [0, 1, 2])
-@pytest.mark.parametrize("family", ["model", "test"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("levels", GRID_LEVELS, ids=["4lv", "2lv", "tiny"])
-def test_query_grid_forward(levels, dtype, family, shape_opt):
-    """Lq == S: the forward runs the LDS-tiled query-grid kernel (boxattn_tile.h).  Same result as
-    the row-gather kernel (variant 7) and as the oracle, for local windows ("model": rows from
-    LDS) and for uniformly random locations ("test": nearly every point takes the global path)."""
-    import bench
-    from boxer_amd import _lib, ops
-    inp = _grid_inputs(levels, dtype, family)
-    v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
-    old = _lib.set_option("tile_shape", shape_opt)
-    _lib.set_option("tile_fwd", 1)
-    try:
-        out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
-        _lib.set_variant(7)
-        ref = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
-        torch.cuda.synchronize()
-    finally:
-        _lib.set_option("tile_shape", old)
-        _lib.set_option("tile_fwd", 0)
-    f64 = lambda t: t.detach().double().cpu().numpy()
-    want = oc.box_attn_forward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn))
-    close(out, want, dtype, "out vs oracle")
-    close(out, f64(ref), dtype, "out vs row-gather kernel")
-    if dtype == torch.float32:
-        assert (out - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
-
-
-def test_query_grid_forward_small_budget_and_margin():
-    """Windows that do not fit (tiny LDS budget) or a margin cap of 1 pixel: the affected points
-    take the global path, results unchanged."""
-    from boxer_amd import _lib, ops
-    inp = _grid_inputs(GRID_LEVELS[0], torch.bfloat16, "model")
-    v, sh, ls, loc, attn = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
-    f64 = lambda t: t.detach().double().cpu().numpy()
-    want = oc.box_attn_forward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn))
-    for name, val in (("tile_rows", 40), ("tile_rows", 2), ("tile_margin_cap", 1)):
-        old = _lib.set_option(name, val)
-        _lib.set_option("tile_fwd", 1)
-        try:
-            out = ops.box_attn_forward(v, sh, ls, loc, attn, 64)
-            torch.cuda.synchronize()
-        finally:
-            _lib.set_option(name, old)
-            _lib.set_option("tile_fwd", 0)
-        close(out, want, torch.bfloat16, "out (%s=%d)" % (name, val))
-
-
-@pytest.mark.parametrize("target", [0, 64, 2048])
-@pytest.mark.parametrize("family", ["model", "test"])
-@pytest.mark.parametrize("levels", GRID_LEVELS, ids=["4lv", "2lv", "tiny"])
-def test_query_grid_backward(levels, family, target):
-    """Lq == S, bf16 storage: grad_value comes from the query-grid backward (boxattn_qgrid.h: tile
-    boxes -> candidate enumeration -> MFMA rounds; no global binning).  Compared with the oracle
-    and with the binned backward (variant 8), with and without the training forward's plan, for
-    several work-item sizes (target records per item: split blocks with partial tiles / groups
-    of 2 and 4 blocks)."""
-    from boxer_amd import _lib, ops
-    inp = _grid_inputs(levels, torch.bfloat16, family)
-    v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
-                                                  "grad_out"))
-    f64 = lambda t: t.detach().double().cpu().numpy()
-    want = oc.box_attn_backward(f64(v), sh.cpu().numpy(), ls.cpu().numpy(), f64(loc), f64(attn),
-                                f64(go))
-    old = _lib.set_option("qg_target", target)
-    _lib.set_option("qg_bwd", 1)
-    try:
-        out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
-        assert plan is not None and plan.kind == 2
-        with_plan = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
-        no_plan = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
-        _lib.set_variant(8)
-        binned = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64)
-        torch.cuda.synchronize()
-    finally:
-        _lib.set_option("qg_target", old)
-        _lib.set_option("qg_bwd", 0)
-    for got, name in ((with_plan, "plan"), (no_plan, "no plan")):
-        close(got[0], want[0], torch.bfloat16, "grad_value (%s)" % name)
-        close(got[1], want[1], torch.float32, "grad_loc (%s)" % name,
-              ignore=on_cell_edge(f64(loc), sh.cpu().numpy()))
-        close(got[2], want[2], torch.float32, "grad_attn (%s)" % name)
-    # same sums as the binned backward up to the fp32 order inside a block + one bf16 rounding
-    d = (with_plan[0].float() - binned[0].float()).abs().max().item()
-    assert d <= 2e-2 * max(1.0, binned[0].float().abs().max().item())
-    assert torch.equal(with_plan[0], no_plan[0])          # deterministic: no atomics anywhere
 
 
 # ------------------------------------------------------------------ pointwise passes (N3)
@@ -1200,13 +1035,13 @@ def test_boxes_in_backward_with_undersized_workspace(monkeypatch):
     value, shapes, lsi, ref, off, kidx, vr, attn, gout = _box_inputs(
         levels, 2, 8, 0, False, False, torch.float32)
     grid = ops.box_grid_forward(ref, off, kidx, vr, 0)
-    real = ops._workspace
+    real = ops._sized_buffer
 
-    def small(value, shapes, lsi, dims):
-        ws, sh, ls = real(value, shapes, lsi, dims)
+    def small(query, value, shapes, lsi, dims, minimum=256):
+        ws, sh, ls = real(query, value, shapes, lsi, dims, minimum)
         return ws[: ws.numel() // 2 // 256 * 256], sh, ls
 
-    monkeypatch.setattr(ops, "_workspace", small)
+    monkeypatch.setattr(ops, "_sized_buffer", small)
     res = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr, 0,
                                          need_ref_grad=True)
     torch.cuda.synchronize()
