@@ -242,6 +242,27 @@ def main():
         dist.barrier()
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     ms_step = float(elapsed) / args.steps * 1e3
+    # The gradient all-reduce's share of the step (reference: DDP in
+    # e2edet/trainer/base_trainer.py:119-129): the same steps once more without it (no_sync: gradients
+    # accumulate locally) -- the difference is the part of the collective that backward does not hide.
+    allreduce = None
+    if dist is not None:
+        dist.barrier()
+        t0 = time.perf_counter()
+        with model.no_sync():
+            for _ in range(args.steps):
+                step()
+        torch.cuda.synchronize()
+        local = torch.tensor([time.perf_counter() - t0], device=device)
+        dist.barrier()
+        dist.all_reduce(local, op=dist.ReduceOp.MAX)
+        ms_local = float(local) / args.steps * 1e3
+        grad_bytes = 4 * n_params
+        allreduce = {"exposed_ms_per_step": round(max(0.0, ms_step - ms_local), 3),
+                     "share_of_step": round(max(0.0, ms_step - ms_local) / ms_step, 3),
+                     "gradient_MB": round(grad_bytes / 1e6, 1), "ms_per_step_without": round(ms_local, 3),
+                     "note": "step time with DDP's bucketed all-reduce (RCCL) minus the same steps under no_sync(); "
+                             "bus bandwidth of the collective itself: tools/rccl_allreduce_bench.py"}
 
     if rank == 0:
         print(json.dumps({
@@ -253,7 +274,7 @@ def main():
             "operator_kernels_ms_per_step": round(op_ms, 3),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "operator_share": round(op_ms / ms_step, 3), "loss": round(float(loss), 4),
-            "data": "synthetic", "scaling": "weak"}), flush=True)
+            "allreduce": allreduce, "data": "synthetic", "scaling": "weak"}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -21,7 +21,7 @@ if not os.path.exists(os.path.join(INCLUDE_DIR, "boxattn.h")):
 # with -fno-slp-vectorize: packed float32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32, which the
 # SLP vectoriser forms from adjacent scalar operations) issued while an MFMA of the same wave is
 # finishing returned wrong results in lanes 48-63 on MI355X with this compiler
-SOURCES = {"boxattn_capi.hip": [], "boxattn_dense.hip": ["-fno-slp-vectorize"]}
+SOURCES = {"boxattn_capi.hip": [], "boxattn_extras.hip": [], "boxattn_dense.hip": ["-fno-slp-vectorize"]}
 HEADERS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))     # every kernel header
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments (its pointers) arrive in
 # SGPRs with the wave instead of through scalar loads at its top (gfx94x / gfx950); every wave of

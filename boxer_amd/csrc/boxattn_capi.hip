@@ -152,9 +152,6 @@ template <typename ST, int G, int VEC> struct GatherUnroll {
     static constexpr int want = VEC == 8 ? u8 : u4;
     static constexpr int value = (want <= 0 || want > G) ? G : want;
 };
-#ifndef BOXATTN_TUNE_HEAD_XCD
-#define BOXATTN_TUNE_HEAD_XCD 1
-#endif
 inline unsigned div_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / d); }
 // index constants of the gather kernels; false if the problem is outside their 32-bit arithmetic
 inline bool gather_idx(const Dims &d, GatherIdx &ix, size_t elem_bytes)
@@ -169,7 +166,7 @@ inline bool gather_idx(const Dims &d, GatherIdx &ix, size_t elem_bytes)
     // (decoder queries with big boxes, random locations) and -2..7 % for the encoder's local
     // windows, where the contiguous query chunks already keep an XCD's rows together.  So: only
     // for decoder-like shapes (few queries against the map) whose per-head rows fit an XCD's L2.
-    ix.head_xcd = (BOXATTN_TUNE_HEAD_XCD && d.H == 8 && (long long)d.Lq * 4 <= d.S &&
+    ix.head_xcd = (d.H == 8 && (long long)d.Lq * 4 <= d.S &&
                    (size_t)d.B * d.S * d.C * elem_bytes <= (3u << 20))
                       ? 1u : 0u;
     return true;
@@ -267,12 +264,6 @@ inline void drain(std::vector<EventPair> &v, double *ms_sum, int *n)
     if (n) *n = cnt;
 }
 
-
-template <typename K> inline hipError_t allow_dynamic_lds(K kernel, size_t bytes)
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 // rider workgroups of a launch: the caller sets ride.grid.n_riders / .shift, the rest follows from the grid
 inline BinRide place_riders(const BinRide *ride_in, unsigned own_blocks, unsigned *total)
@@ -507,10 +498,7 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 
 
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
-#ifndef BOXATTN_TUNE_CHUNK
-#define BOXATTN_TUNE_CHUNK 1024
-#endif
-constexpr int kChunk = BOXATTN_TUNE_CHUNK;   // records per work item (upper bound)
+constexpr int kChunk = 1024;   // records per work item (upper bound)
 // Records per work item.  One wavefront works an item off 64 records a round, and a round is a
 // chain of dependent latencies (~3-5 us), so the kernel lasts at least rounds-per-item rounds:
 // with few sample points (the decoders: 300 queries) 1 024-record items leave a handful of waves
@@ -930,10 +918,8 @@ hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::va
 // dispatcher hands them out as waves retire -- dynamic load balancing without a work-queue atomic (a
 // persistent-waves version with a software queue was 15 % slower).  The kernels map workgroups to (slice,
 // worker) themselves (XCD affinity), hence the 8-aligned grid.
-#ifndef BOXATTN_TUNE_ACC_WG_CAP
-#define BOXATTN_TUNE_ACC_WG_CAP 1024   // per slice; beyond that a workgroup takes several items (its next one in flight);
-                                       // 256 / 512 / 1024 / 3072 / 6144: C5 99 / 85 / 83 / 93 / 111 us, C2 67 / 54 / 54 / 55 / 54
-#endif
+constexpr int kAccWgCap = 1024;   // accumulate workgroups per slice; beyond that a workgroup takes several items (its next one in
+                                  // flight); 256 / 512 / 1024 / 3072 / 6144: C5 99 / 85 / 83 / 93 / 111 us, C2 67 / 54 / 54 / 55 / 54
 template <typename ST, int G, bool INST>
 int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, const float *loc, const float *w_sp,
                       const float *w_lv, const Dims &d, const BinPlan &plan, const int *offsets, const int4 *items,
@@ -942,7 +928,7 @@ int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, cons
 {
     constexpr int C = 4 * G;
     const int ns = d.B * d.H, ns8 = (ns + 7) / 8 * 8;
-    const int wg_per_slice = std::min(BOXATTN_TUNE_ACC_WG_CAP, std::max(1, plan.item_cap));
+    const int wg_per_slice = std::min(kAccWgCap, std::max(1, plan.item_cap));
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdAccum], st);
     if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
         if (acc == kAccTr) {
@@ -1426,44 +1412,6 @@ static int grid_dims(int ref_dim, int ref_per_head, int V, int angle_mode, int B
     return ((size_t)B * Lq == 0) ? 2 : 1;                       // 2: nothing to do
 }
 
-int boxattn_grid_fwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
-                         int V, int angle_mode, const float *kernel_idx,
-                         const float *valid_ratios, int B, int Lq, int H, int L, int P,
-                         float *grid, void *stream)
-{
-    GridDims d{};
-    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, d);
-    if (ok == 2) return 0;
-    if (ok != 1 || !ref || !offsets || !kernel_idx || !grid) return (int)hipErrorInvalidValue;
-    const size_t n_pts = (size_t)B * Lq * H * L * P;
-    const size_t blocks = (n_pts + 255) / 256;
-    if (blocks > 0x7fffffffu) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(grid_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       ref, offsets, kernel_idx, valid_ratios, d, n_pts, grid);
-    return finish();
-}
-
-int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const float *offsets,
-                         int V, int angle_mode, const float *kernel_idx,
-                         const float *valid_ratios, const float *grad_grid, int B, int Lq, int H,
-                         int L, int P, float *grad_offsets, float *grad_ref_rows, void *stream)
-{
-    GridDims d{};
-    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, d);
-    if (ok == 2) return 0;
-    if (ok != 1 || !ref || !offsets || !kernel_idx || !grad_grid || !grad_offsets)
-        return (int)hipErrorInvalidValue;
-    const size_t n_rows = (size_t)B * Lq * H * L;
-    const size_t blocks = (n_rows * 4 + 255) / 256;
-    if (blocks > 0x7fffffffu) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(grid_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       ref, offsets, kernel_idx, valid_ratios, grad_grid, d, n_rows, grad_offsets,
-                       grad_ref_rows);
-    return finish();
-}
-
-
-
 // ---- box attention straight from boxes (second step) ----------------------
 static int grid_src(const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
                     int angle_mode, const float *kernel_idx, const float *valid_ratios, int B, int Lq,
@@ -1543,118 +1491,6 @@ int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const
                                         DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
                                         grad_attn, nullptr, shapes_host, lsi_host, workspace,
                                         workspace_bytes, nullptr, 0, ST_, &gs);
-}
-
-}  // extern "C"
-
-// ---- pointwise work around the operator ---------------------------------
-// lanes per row of the vector kernels (rows of 4, 8, 16, 32 or 64 values, 16-byte aligned
-// tensors), 0: the one-thread-per-row kernels
-template <typename T>
-static int softmax_group(int n, const T *typed, const float *f32)
-{
-    if (n % 4 != 0 || (n / 4 & (n / 4 - 1)) != 0 || n > 64) return 0;
-    return aligned(typed, 16) && aligned(f32, 16) ? n / 4 : 0;
-}
-
-template <typename T>
-static int softmax_fwd(const T *logits, long long rows, int n, float *attn, hipStream_t st)
-{
-    if (rows < 0 || n <= 0 || n > 64) return (int)hipErrorInvalidValue;
-    if (rows == 0) return 0;
-    if (!logits || !attn) return (int)hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)((rows + 255) / 256);
-    const int g = softmax_group(n, logits, attn);
-    const size_t total = (size_t)rows * n;
-    const unsigned vblocks = (unsigned)((total / 4 + 255) / 256);
-#define BOXATTN_SOFTMAX_VEC(G) \
-    hipLaunchKernelGGL((softmax_vec_fwd_kernel<T, G>), dim3(vblocks), dim3(256), 0, st, logits, total, attn)
-    if (g == 1) BOXATTN_SOFTMAX_VEC(1);
-    else if (g == 2) BOXATTN_SOFTMAX_VEC(2);
-    else if (g == 4) BOXATTN_SOFTMAX_VEC(4);
-    else if (g == 8) BOXATTN_SOFTMAX_VEC(8);
-    else if (g == 16) BOXATTN_SOFTMAX_VEC(16);
-#undef BOXATTN_SOFTMAX_VEC
-    else if (n <= 16)
-        hipLaunchKernelGGL((softmax_rows_fwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, logits,
-                           (size_t)rows, n, attn);
-    else
-        hipLaunchKernelGGL((softmax_rows_fwd_kernel<T, 64>), dim3(blocks), dim3(256), 0, st, logits,
-                           (size_t)rows, n, attn);
-    return finish();
-}
-template <typename T>
-static int softmax_bwd(const float *attn, const float *grad_attn, long long rows, int n,
-                       T *grad_logits, hipStream_t st)
-{
-    if (rows < 0 || n <= 0 || n > 64) return (int)hipErrorInvalidValue;
-    if (rows == 0) return 0;
-    if (!attn || !grad_attn || !grad_logits) return (int)hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)((rows + 255) / 256);
-    const int g = aligned(grad_attn, 16) ? softmax_group(n, grad_logits, attn) : 0;
-    const size_t total = (size_t)rows * n;
-    const unsigned vblocks = (unsigned)((total / 4 + 255) / 256);
-#define BOXATTN_SOFTMAX_VEC(G) \
-    hipLaunchKernelGGL((softmax_vec_bwd_kernel<T, G>), dim3(vblocks), dim3(256), 0, st, attn, \
-                       grad_attn, total, grad_logits)
-    if (g == 1) BOXATTN_SOFTMAX_VEC(1);
-    else if (g == 2) BOXATTN_SOFTMAX_VEC(2);
-    else if (g == 4) BOXATTN_SOFTMAX_VEC(4);
-    else if (g == 8) BOXATTN_SOFTMAX_VEC(8);
-    else if (g == 16) BOXATTN_SOFTMAX_VEC(16);
-#undef BOXATTN_SOFTMAX_VEC
-    else if (n <= 16)
-        hipLaunchKernelGGL((softmax_rows_bwd_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, attn,
-                           grad_attn, (size_t)rows, n, grad_logits);
-    else
-        hipLaunchKernelGGL((softmax_rows_bwd_kernel<T, 64>), dim3(blocks), dim3(256), 0, st, attn,
-                           grad_attn, (size_t)rows, n, grad_logits);
-    return finish();
-}
-
-template <typename T>
-static int value_prep(const T *value, const unsigned char *mask, long long rows, int d,
-                      uint16_t *out, hipStream_t st)
-{
-    if (rows < 0 || d <= 0 || d % 8 != 0) return (int)hipErrorInvalidValue;
-    if (rows == 0) return 0;
-    if (!value || !out || !aligned(value, 16) || !aligned(out, 16)) return (int)hipErrorInvalidValue;
-    const size_t n8 = (size_t)rows * d / 8;
-    hipLaunchKernelGGL((value_mask_cast_kernel<T>), dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0,
-                       st, value, mask, (size_t)rows, d, out);
-    return finish();
-}
-
-extern "C" {
-
-int boxattn_softmax_fwd_f32(const float *logits, long long rows, int n, float *attn, void *stream)
-{
-    return softmax_fwd<float>(logits, rows, n, attn, (hipStream_t)stream);
-}
-int boxattn_softmax_fwd_bf16(const uint16_t *logits, long long rows, int n, float *attn, void *stream)
-{
-    return softmax_fwd<bf16_t>(logits, rows, n, attn, (hipStream_t)stream);
-}
-int boxattn_softmax_bwd_f32(const float *attn, const float *grad_attn, long long rows, int n,
-                            float *grad_logits, void *stream)
-{
-    return softmax_bwd<float>(attn, grad_attn, rows, n, grad_logits, (hipStream_t)stream);
-}
-int boxattn_softmax_bwd_bf16(const float *attn, const float *grad_attn, long long rows, int n,
-                             uint16_t *grad_logits, void *stream)
-{
-    return softmax_bwd<bf16_t>(attn, grad_attn, rows, n, grad_logits, (hipStream_t)stream);
-}
-
-int boxattn_value_prep_f32(const float *value, const unsigned char *mask, long long rows, int d,
-                           uint16_t *out, void *stream)
-{
-    return value_prep<float>(value, mask, rows, d, out, (hipStream_t)stream);
-}
-int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, long long rows, int d,
-                            uint16_t *out, void *stream)
-{
-    return value_prep<bf16_t>(value, mask, rows, d, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -88,3 +88,22 @@ def test_bench_self_launcher_starts_its_ranks(tmp_path, capfd):
     assert rc == 0
     assert "SUM=3 WORLD=2 LOCAL=0" in capfd.readouterr().out
     assert env_before == {k: os.environ.get(k) for k in env_before}      # parent env untouched
+
+
+@pytest.mark.timeout(300)
+def test_allreduce_bandwidth_tool_world2(capfd):
+    """tools/rccl_allreduce_bench.py (RCCL all-reduce bus bandwidth at 25 / 160 MB) with its own
+    launcher, gloo on the host at world size 2 and small messages: one JSON line per size, busbw = algbw * 2 (N-1)/N."""
+    import json
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "rccl_allreduce_bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, tool, "--gpus", "2", "--backend", "gloo", "--device", "cpu", "--iters", "3",
+                          "--warmup", "1", "--sizes-mb", "0.5", "2"], capture_output=True, text=True, env=env,
+                         timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert [l["bytes"] for l in lines] == [500000, 2000000]
+    for l in lines:
+        assert l["n_ranks"] == 2 and l["checked"] and l["ms"] > 0
+        assert abs(l["busbw_GBs"] - l["algbw_GBs"] * 2 * (2 - 1) / 2) < 0.02

@@ -487,6 +487,66 @@ def test_modules_match_reference_goldens():
     close(out, g["out"], torch.float64, "Box3dAttention(fixed) out")
 
 
+# The opt-in paths of SURVEY.md 8(f) N1 / N3 against the SAME reference goldens:
+# fused_grid 1 (grid kernels), 2 (boxes straight into the sampling kernels), fused_pointwise (one-pass
+# softmax / mask-fill + cast), native bf16 storage.  They are float32 / bf16 paths, so the modules run in
+# float32 here and are compared with the float64 goldens at the float32 (bf16) tolerance.
+@pytest.mark.parametrize("native_bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("fused_pointwise", [False, True], ids=["torch_pointwise", "fused_pointwise"])
+@pytest.mark.parametrize("fused_grid", [0, 1, 2])
+def test_fused_module_paths_match_reference_goldens(fused_grid, fused_pointwise, native_bf16):
+    from boxer_amd import Box3dAttention, BoxAttention, InstanceAttention
+    d, nl, nh = 32, 2, 4
+    tol = 2e-2 if native_bf16 else 1e-4
+
+    def f32(a):
+        t = dev(a)
+        return t.float() if t.is_floating_point() else t
+
+    def args(g, with_mask=True, with_ratio=True):
+        return (f32(g["query"]), f32(g["value"]), dev(g["shapes"]),
+                dev(g["v_mask"]) if with_mask else None, dev(g["lsi"]),
+                f32(g["ratios"]) if with_ratio else None, f32(g["ref_windows"]))
+
+    def make(cls, g, **kw):
+        m = _load_module(cls, g, **kw).float()
+        m.fused_grid, m.fused_pointwise, m.native_bf16 = fused_grid, fused_pointwise, native_bf16
+        return m
+
+    def run(m, a):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native_bf16):
+            return m(*a)
+
+    def check(got, want, what):
+        got = got.detach().double().cpu().numpy()
+        err = float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max()))
+        assert err <= tol, "%s (fused_grid=%s pointwise=%s bf16=%s): %.3e > %.0e" % (
+            what, fused_grid, fused_pointwise, native_bf16, err, tol)
+
+    g = golden_io.load("G7_module_box")
+    m = make(BoxAttention, g, d_model=d, num_level=nl, num_head=nh, kernel_size=2)
+    out, attn = run(m, args(g))
+    check(out, g["out"], "BoxAttention out")
+    check(attn, g["attn"], "BoxAttention attn")
+    g = golden_io.load("G7_module_box_perhead")
+    check(run(m, args(g, False, False))[0], g["out"], "BoxAttention per-head out")
+    for ks in (4, 14):
+        g = golden_io.load("G7_module_inst_k%d" % ks)
+        m = make(InstanceAttention, g, d_model=d, num_level=nl, num_head=nh, kernel_size=ks)
+        m.inferencing = False
+        out, mask_out, (sw, lw) = run(m, args(g))
+        check(out, g["out"], "InstanceAttention out")
+        check(mask_out, g["mask_out"], "InstanceAttention mask_out")
+        check(sw, g["spatial_w"], "spatial_w")
+        check(lw, g["level_w"], "level_w")
+    g = golden_io.load("G7_module_box3d_rot")
+    m = make(Box3dAttention, g, d_model=d, num_level=nl, num_head=nh, with_rotation=True, kernel_size=2)
+    check(run(m, args(g))[0], g["out"], "Box3dAttention(rot) out")
+    g = golden_io.load("G7_module_box3d_fixed")
+    m = make(Box3dAttention, g, d_model=d, num_level=nl, num_head=nh, with_rotation=False, kernel_size=3)
+    check(run(m, args(g, False, False))[0], g["out"], "Box3dAttention(fixed) out")
+
+
 # ------------------------------------------------------------------ box -> grid (opt-in)
 def _torch_grid(ref, off, kidx, vr, angle_mode):
     """The reference modules' _where_to_attend after the offset projection

@@ -115,6 +115,47 @@ def test_layer_matches_reference_golden(name):
     np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=0, atol=1e-9)
 
 
+def _run_layer(name, layer, g, cast=lambda t: t):
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    f = lambda k: cast(_dev(g[k]))
+    ref = f("ref_windows")
+    if "enc2d" in name:
+        return layer(f("src"), f("pos"), shapes, _dev(g["v_mask"]), lsi, f("ratios"), ref)
+    if "enc3d" in name:
+        return layer(f("src"), f("pos"), shapes, lsi, ref)
+    if "dec3d" in name:
+        return layer(f("tgt"), f("query_pos"), f("memory"), shapes, lsi, ref)
+    if "mask" in name:
+        layer.inferencing = False
+        layer.multihead_attn.inferencing = False
+    return layer(f("tgt"), f("query_pos"), f("memory"), shapes, _dev(g["v_mask"]), lsi, f("ratios"), ref)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused_grid,fused_pointwise,native_bf16",
+                         [(1, False, False), (2, False, False), (0, True, False), (2, True, False),
+                          (1, True, True), (2, True, True)],
+                         ids=["grid1", "grid2", "pointwise", "grid2+pointwise", "grid1+pointwise+bf16",
+                              "grid2+pointwise+bf16"])
+@pytest.mark.parametrize("name", sorted(LAYER_CASES))
+def test_layer_with_fused_paths_matches_reference_golden(name, fused_grid, fused_pointwise, native_bf16):
+    """The opt-in paths of SURVEY.md 8(f) N1 / N3 (grid kernels, boxes straight into the sampling kernels,
+    one-pass softmax / mask-fill + cast, bf16 storage) inside the reference's encoder / decoder layers,
+    against the goldens the reference's own layer classes produced (G8) -- float32 / bf16 runs, so at
+    those types' tolerances."""
+    from boxer_amd.modules import _BoxAttentionBase as _AttentionBase
+    layer, g = build(name)
+    layer = layer.cuda().float()
+    for m in layer.modules():
+        if isinstance(m, _AttentionBase):
+            m.fused_grid, m.fused_pointwise, m.native_bf16 = fused_grid, fused_pointwise, native_bf16
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native_bf16):
+        out = _run_layer(name, layer, g, cast=lambda t: t.float() if t.is_floating_point() else t)
+    want = g["out"]
+    err = float(np.abs(out.detach().double().cpu().numpy() - want).max()) / max(1.0, float(np.abs(want).max()))
+    assert err <= (3e-2 if native_bf16 else 2e-4), (name, err)
+
+
 @pytest.mark.gpu
 def test_bev_encoder_layer_runs_on_pillar_features():
     """pillar features -> BEV canvas -> two levels -> one BoxeR-3D encoder layer
