@@ -44,14 +44,14 @@ _SIGNATURES = {
 _WS_SIGNATURES = {
     # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, plan, plan_bytes, stream
     "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
-                                                       _vp],
+                                                       _i, _vp],
     "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
-                                                        ctypes.c_size_t, _vp],
-    # forward args + shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, int *plan_built, stream
+                                                        ctypes.c_size_t, _i, _vp],
+    # forward args + shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, int *plan_built, stream
     "boxattn_fwd_train": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
-                                                      _vp, _vp],
+                                                      _i, _vp, _vp],
     "instattn_fwd_train": [_vp] * 6 + _DIMS + [_vp] * 2 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
-                                                          ctypes.c_size_t, _vp, _vp],
+                                                          ctypes.c_size_t, _i, _vp, _vp],
 }
 _HL_SIGNATURES = {
     # forward args + shapes_host, lsi_host, stream
@@ -66,6 +66,7 @@ _GRIDATTN_SIGNATURES = {
                            [_vp, _vp, _vp, ctypes.c_size_t, _vp],
 }
 NOT_ELIGIBLE = -2
+HINT_NOT_LOCAL = 1          # BOXATTN_HINT_NOT_LOCAL
 _ll = ctypes.c_longlong
 _POINTWISE_SIGNATURES = {
     "boxattn_softmax_fwd_f32": [_vp, _ll, _i, _vp, _vp],

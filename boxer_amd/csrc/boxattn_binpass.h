@@ -45,7 +45,10 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
 
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     static_assert(PT == 1 || PT == 4, "points per thread and step");
-    constexpr int U = PT == 4 ? 2 : 4;            // groups of PT points per thread per step (loads in flight)
+#ifndef BOXATTN_TUNE_BIN_U
+#define BOXATTN_TUNE_BIN_U 2
+#endif
+    constexpr int U = PT == 4 ? BOXATTN_TUNE_BIN_U : 4;     // groups of PT points per thread per step (loads in flight)
     const size_t pid0 = (((size_t)b * Lq + q0) * H + h) * LP;     // first point of query q0
     const size_t qstride = (size_t)H * LP * qstep;           // points between this WG's queries
     const int LPG = LP / PT, n_grp = n_q * LPG;               // groups per query, groups of this WG
@@ -183,6 +186,10 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
 {
     static_assert(THREADS == 256, "4 wave sums per scan quantity");
     if (id >= r.grid.n_riders) return;
+#ifndef BOXATTN_TUNE_RIDE_PRIO
+#define BOXATTN_TUNE_RIDE_PRIO 0
+#endif
+    if (BOXATTN_TUNE_RIDE_PRIO) __builtin_amdgcn_s_setprio(BOXATTN_TUNE_RIDE_PRIO);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
     const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;
@@ -213,6 +220,7 @@ template <int THREADS>
 __device__ __forceinline__ void bin_fill_ride(const BinRide r, unsigned id, int *lds)
 {
     if (id >= r.grid.n_riders) return;
+    if (BOXATTN_TUNE_RIDE_PRIO) __builtin_amdgcn_s_setprio(BOXATTN_TUNE_RIDE_PRIO);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
     const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;

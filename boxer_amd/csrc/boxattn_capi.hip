@@ -36,7 +36,7 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
        kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
        kOptRiders = 15,       // count / scan / fill / combine inside the forward, point-gradient and accumulate launches:
-                              // 0 default (on), 1 off (launches of their own)
+                              // 0 default (on), 1 off (launches of their own), 2 on except the combine (its own launch)
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
        kOptAccF32 = 19,       // float32 box attention, C = 32: accumulate on v_mfma_f32_32x32x2_f32: 0 / 1 off (VALU list walk), 2 on
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
@@ -285,7 +285,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                const typename Storage<ST>::compute *w_lv, const Dims &d, ST *out, ST *mask,
                hipStream_t st, const int64_t *shapes_host = nullptr,
                const int64_t *lsi_host = nullptr, const BinRide *count_ride = nullptr,
-               bool *ride_taken = nullptr)
+               bool *ride_taken = nullptr, bool allow_dense = true, unsigned long long *stats = nullptr)
 {
     if (ride_taken) *ride_taken = false;
     if (!d.valid()) return (int)hipErrorInvalidValue;
@@ -305,11 +305,11 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                         out)) {
             if constexpr (!INST && std::is_same<ST, bf16_t>::value) {     // encoder case: window-staged matrix-core forward
                 DensePlan dp;
-                if (opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
+                if (allow_dense && opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
                     aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp)) {
                     ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
                     launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)),
-                                     count_ride ? *count_ride : BinRide{}, st);
+                                     count_ride ? *count_ride : BinRide{}, stats, st);
                     if (count_ride && ride_taken) *ride_taken = true;
                     return finish();
                 }
@@ -664,6 +664,11 @@ inline ScratchLayout scratch_layout(const Dims &d, const BinPlan &p, bool wide)
     return w;
 }
 
+// The caller's state buffer (include/boxattn.h): [kDenseStatSlots pairs of uint64 locality counters = 1 KiB]
+// [tickets: B * H * kRideTickets ints].  The counters come FIRST, at a fixed place: one buffer serves calls of
+// every shape on its stream, and what one shape's calls add to must never be another shape's tickets.
+constexpr size_t kStatBytes = (size_t)kDenseStatSlots * 2 * sizeof(unsigned long long);
+
 // May the count / fill passes and the scans of this plan run as riders (boxattn_ride.h)?
 inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
 {
@@ -980,11 +985,12 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     if (!filled) launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill);
     // in-launch combine: the fill riders have cleared the blocks' tickets
     ChunkCombine cc{};
-    if (filled) cc = ChunkCombine{(int *)(sbuf + sl.ctickets), combos, plan.nblk, plan.pslot_cap};
+    const bool own_combine = !filled || opt(kOptRiders) == 2;
+    if (!own_combine) cc = ChunkCombine{(int *)(sbuf + sl.ctickets), combos, plan.nblk, plan.pslot_cap};
     int rc = launch_accumulate<ST, G, INST>(acc, grad_out, grad_mask, loc, w_sp, w_lv, d, plan, offsets, items,
                                             n_items, records, grad_value, partials, cc, st);
     if (rc) return rc;
-    if (!filled) {
+    if (own_combine) {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
         hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
                            n_items, partials, combine_plan(plan), d.S, d.H, grad_value);
@@ -999,7 +1005,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                  size_t workspace_bytes, const void *plan_buf, size_t plan_bytes, hipStream_t st,
+                  size_t workspace_bytes, const void *plan_buf, size_t plan_bytes, int hints, hipStream_t st,
                   const GridSrc *gs = nullptr)
 {
     constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
@@ -1047,7 +1053,8 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     char *sbuf = plan_ready ? ws : ws + pl.total;
     int rc = 0;
     DensePlan dense;
-    const DensePlan *dp = kBf16 && !INST && make_dense_plan(d, shapes_host, lsi_host, dense) ? &dense : nullptr;
+    const DensePlan *dp = kBf16 && !INST && !(hints & BOXATTN_HINT_NOT_LOCAL) &&
+                                  make_dense_plan(d, shapes_host, lsi_host, dense) ? &dense : nullptr;
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
@@ -1069,9 +1076,15 @@ template <typename ST, bool INST>
 int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                      const float *w_sp, const float *w_lv, const Dims &d, ST *out, ST *mask,
                      const int64_t *shapes_host, const int64_t *lsi_host, void *plan_buf,
-                     size_t plan_bytes, void *state, size_t state_bytes, int *plan_built, hipStream_t st)
+                     size_t plan_bytes, void *state, size_t state_bytes, int hints, int *plan_built,
+                     hipStream_t st)
 {
     if (plan_built) *plan_built = 0;
+    const bool allow_dense = !(hints & BOXATTN_HINT_NOT_LOCAL);
+    // the locality counters of the window-staged forward, then the riders' tickets
+    const size_t tbytes = (size_t)std::max(0, d.B) * (size_t)std::max(0, d.H) * kRideTickets * sizeof(int);
+    const bool have_state = state && state_bytes >= kStatBytes + tbytes && aligned(state, 8);
+    unsigned long long *stats = have_state ? (unsigned long long *)state : nullptr;
     BinPlan plan;
     bool ok = (g_variant == 0 || g_variant == 3) && plan_buf && d.valid() &&
               d.n_value() && d.n_qh() && make_plan(d, shapes_host, lsi_host, plan) &&
@@ -1086,7 +1099,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
     }
     if (!ok)
         return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
-                                    shapes_host, lsi_host);
+                                    shapes_host, lsi_host, nullptr, nullptr, allow_dense, stats);
     char *pbuf = (char *)plan_buf;
     const int flavour = bin_flavour<ST, INST>(d, loc, w_sp);
     bool taken = false;
@@ -1096,18 +1109,18 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         // persistent ticket buffer (one per stream: calls on a stream never overlap); without it the tickets live
         // in the -- possibly fresh -- plan buffer and are cleared by a launch of their own (~5 us in front of
         // the forward kernel).
-        const size_t tbytes = (size_t)d.B * d.H * kRideTickets * sizeof(int);
         BinRide ride = make_ride(loc, w_sp, d, plan, pl, pbuf, nullptr, nullptr, flavour, false);
-        if (state && state_bytes >= tbytes && aligned(state, 4)) {
-            ride.tickets = (int *)state;
+        if (have_state) {
+            ride.tickets = (int *)((char *)state + kStatBytes);
         } else {
             hipError_t e = zero_async(pbuf + pl.tickets, tbytes, st);
             if (e != hipSuccess) return (int)e;
         }
         rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st, shapes_host, lsi_host,
-                                  &ride, &taken);
+                                  &ride, &taken, allow_dense, stats);
     } else {
-        rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st, shapes_host, lsi_host);
+        rc = launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st, shapes_host, lsi_host,
+                                  nullptr, nullptr, allow_dense, stats);
     }
     if (rc) return rc;
     if (!taken)
@@ -1129,38 +1142,38 @@ int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64
                           const float *loc, const float *attn, int B, int S, int H, int C, int L,
                           int Lq, int P, float *out, const int64_t *shapes_host,
                           const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                          size_t state_bytes, int *plan_built, void *stream)
+                          size_t state_bytes, int hints, int *plan_built, void *stream)
 {
     return launch_fwd_train<float, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out, nullptr,
-                                          shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, plan_built, ST_);
+                                          shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, plan_built, ST_);
 }
 int boxattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *attn, int B, int S, int H, int C, int L,
                            int Lq, int P, uint16_t *out, const int64_t *shapes_host,
                            const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                           size_t state_bytes, int *plan_built, void *stream)
+                           size_t state_bytes, int hints, int *plan_built, void *stream)
 {
     return launch_fwd_train<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, DIMS, out, nullptr,
-                                           shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, plan_built, ST_);
+                                           shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, plan_built, ST_);
 }
 int instattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *spatial_w, const float *level_w, int B,
                            int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
                            const int64_t *shapes_host, const int64_t *lsi_host, void *plan,
-                           size_t plan_bytes, void *state, size_t state_bytes, int *plan_built, void *stream)
+                           size_t plan_bytes, void *state, size_t state_bytes, int hints, int *plan_built, void *stream)
 {
     return launch_fwd_train<float, true>(value, shapes, lsi, loc, spatial_w, level_w, DIMS, out, mask_out,
-                                         shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, plan_built, ST_);
+                                         shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, plan_built, ST_);
 }
 int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                             const float *loc, const float *spatial_w, const float *level_w, int B,
                             int S, int H, int C, int L, int Lq, int P, uint16_t *out,
                             uint16_t *mask_out, const int64_t *shapes_host,
                             const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                            size_t state_bytes, int *plan_built, void *stream)
+                            size_t state_bytes, int hints, int *plan_built, void *stream)
 {
     return launch_fwd_train<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, DIMS, out, mask_out,
-                                          shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, plan_built, ST_);
+                                          shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, plan_built, ST_);
 }
 
 size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
@@ -1173,7 +1186,10 @@ size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq
     return plan_layout(d, plan).total;
 }
 
-size_t boxattn_state_bytes(int B, int H) { return (size_t)std::max(0, B) * (size_t)std::max(0, H) * kRideTickets * sizeof(int); }
+size_t boxattn_state_bytes(int B, int H)
+{
+    return kStatBytes + (size_t)std::max(0, B) * (size_t)std::max(0, H) * kRideTickets * sizeof(int);
+}
 
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                                    const int64_t *shapes_host, const int64_t *lsi_host)
@@ -1192,22 +1208,22 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
                        void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes,
-                       void *stream)
+                       int hints, void *stream)
 {
     return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                        grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                       workspace, workspace_bytes, plan, plan_bytes, ST_);
+                                       workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
 }
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, void *stream)
+                        const void *plan, size_t plan_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                         grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                        workspace, workspace_bytes, plan, plan_bytes, ST_);
+                                        workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
 }
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
@@ -1215,11 +1231,11 @@ int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, void *stream)
+                        const void *plan, size_t plan_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                       grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, ST_);
+                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
 }
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
@@ -1227,11 +1243,11 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         const void *plan, size_t plan_bytes, void *stream)
+                         const void *plan, size_t plan_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                        grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, ST_);
+                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
 }
 
 
@@ -1469,7 +1485,7 @@ int boxattn_bwd_ws_grid_f32(const float *value, const int64_t *shapes, const int
     return launch_bwd_ws<float, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
                                        DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                       workspace_bytes, nullptr, 0, ST_, &gs);
+                                       workspace_bytes, nullptr, 0, 0, ST_, &gs);
 }
 int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                              const float *grid, const float *attn, const uint16_t *grad_out,
@@ -1490,7 +1506,7 @@ int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
                                         DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
                                         grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                        workspace_bytes, nullptr, 0, ST_, &gs);
+                                        workspace_bytes, nullptr, 0, 0, ST_, &gs);
 }
 
 }  // extern "C"

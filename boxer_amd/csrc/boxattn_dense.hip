@@ -34,14 +34,15 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
 }
 
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride_in, hipStream_t st)
+                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride_in,
+                      unsigned long long *stats, hipStream_t st)
 {
     unsigned total = 0;
     const BinRide ride = place_riders(ride_in, dense_blocks(dp), &total);
 #define BOXATTN_DENSE_FWD(LV_)                                                                       \
     case LV_:                                                                                        \
         hipLaunchKernelGGL((fwd_dense_kernel<LV_>), dim3(total), dim3(256), 0, st, value, loc, attn, out, \
-                           dp, value_bytes, ride);                                                   \
+                           dp, value_bytes, ride, stats);                                            \
         break;
     switch (dp.L) {
         BOXATTN_DENSE_FWD(1) BOXATTN_DENSE_FWD(2) BOXATTN_DENSE_FWD(3) BOXATTN_DENSE_FWD(4)

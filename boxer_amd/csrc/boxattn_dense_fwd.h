@@ -56,7 +56,8 @@ constexpr int kDenseZeroSlot = kDenseSlots - 1;        // a 64-byte row of zeros
 template <int L>
 __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
-    bf16_t *__restrict__ out, DensePlan pl, unsigned value_bytes, BinRide ride)
+    bf16_t *__restrict__ out, DensePlan pl, unsigned value_bytes, BinRide ride,
+    unsigned long long *__restrict__ stats)
 {
     constexpr int C = 32, P = 4, LP = L * P;
     constexpr int kBias = 4096;                         // keeps the packed slot offset non-negative
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     const int jc = (lane >> 2) & 3, qs = lane & 3;
     const unsigned odd_mask = 0u - (unsigned)(lane & 1);
     const int src_lane4 = ((lane & 48) + 4 * qs) * 4;              // ds_bpermute address of lane 0 of that quad
+    unsigned n_slow = 0, n_act = 0;                                // locality statistics of this wave (stats != nullptr)
     fwd_f32x4 acc[8];                                              // matrix cores: channel 4 m + r, rows = weight terms
     float accv[8];                                                 // VALU (global path): channels 8 r .. 8 r + 7
 #pragma unroll
@@ -164,6 +166,8 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
             }
         }
         const unsigned long long slow_lanes = __builtin_amdgcn_ballot_w64(slow);
+        n_slow += (unsigned)__builtin_popcountll(slow_lanes);
+        n_act += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
         if (slow_lanes != 0ull) {                                  // wave-uniform: the global path
             constexpr unsigned kNoRow = 0x80000000u;               // outside the buffer: the load returns zeros
             const unsigned row0 = t.b * (unsigned)hot.S + (unsigned)T.start;
@@ -194,6 +198,17 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
                 }
             }
         }
+    }
+    // How local were this wave's points?  {points served from global memory, points inside the window test}
+    // into one of kDenseStatSlots pairs of monotonic 64-bit counters of the caller's state buffer -- from one tile
+    // in 61 only (a prime: the sample walks through the XCDs' bands of the map; every wave of every tile doing it
+    // was 15 k same-line atomics, +20 us).  Fire and forget: nobody waits for these atomics.  The caller reads the
+    // counters now and then and, when most points miss their windows, asks for the row-gather kernels instead
+    // (hints, include/boxattn.h).
+    if (stats && lane == 0 && role.id % 61u == 0u) {
+        unsigned long long *slot = stats + 2 * (((role.id / 61u) * 4u + (unsigned)wv) & (kDenseStatSlots - 1));
+        __hip_atomic_fetch_add(slot, (unsigned long long)n_slow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(slot + 1, (unsigned long long)n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- lane r of the quad holds channels r, 4 + r, .. 28 + r from the matrix cores: through LDS into the
     //      channel-contiguous order of the VALU sums, then one 16-byte piece of the query's row per lane

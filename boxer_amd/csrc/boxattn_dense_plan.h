@@ -20,6 +20,7 @@ constexpr int kDenseSlotBytes = 80;        // one staged pixel: 64 bytes of bf16
 #define BOXATTN_DENSE_SLOTS 480
 #endif
 constexpr int kDenseSlots = BOXATTN_DENSE_SLOTS;   // staged pixels per workgroup (480: 38 400 bytes)
+constexpr int kDenseStatSlots = 64;        // pairs of 64-bit locality counters in the caller's state buffer (power of two)
 
 struct DenseLevel {
     int H, W, start;         // map size, first row of the level in `value`
@@ -68,9 +69,10 @@ void launch_pointgrad_dense(const uint16_t *value, const float *loc, const float
                             float *grad_attn, unsigned value_bytes, hipStream_t st, const BinRide &ride);
 
 // out of bf16 box attention on a query grid (boxattn_dense_fwd.h) (+ the training forward's count riders
-// and the scans chained behind them, if any)
+// and the scans chained behind them, if any; stats: kDenseStatSlots pairs of locality counters or null)
 void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn, uint16_t *out,
-                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride, hipStream_t st);
+                      const DensePlan &dp, unsigned value_bytes, const BinRide &ride,
+                      unsigned long long *stats, hipStream_t st);
 
 // The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
 // because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per

@@ -177,13 +177,13 @@ std::vector<at::Tensor> box_attn_backward(const at::Tensor &value, const at::Ten
                                     attn_weight.data_ptr<float>(), grad_output.data_ptr<float>(),
                                     d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(),
                                     grad_loc.data_ptr<float>(), grad_attn.data_ptr<float>(), h.sh(),
-                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, st);
+                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, 0, st);
         else
             rc = boxattn_bwd_ws_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                                      attn_weight.data_ptr<float>(), bf(grad_output), d.B, d.S, d.H,
                                      d.C, d.L, d.Lq, d.P, bf(grad_value), grad_loc.data_ptr<float>(),
                                      grad_attn.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                                     (size_t)ws.numel(), nullptr, 0, st);
+                                     (size_t)ws.numel(), nullptr, 0, 0, st);
     }
     check_rc(rc, "boxattn_bwd");
     return {grad_value, grad_loc, grad_attn};
@@ -268,14 +268,14 @@ std::vector<at::Tensor> instance_attn_backward(
                 grad_output.data_ptr<float>(), grad_mask_output.data_ptr<float>(), d.B, d.S, d.H,
                 d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(), grad_loc.data_ptr<float>(),
                 grad_sw.data_ptr<float>(), grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                (size_t)ws.numel(), nullptr, 0, st);
+                (size_t)ws.numel(), nullptr, 0, 0, st);
         else
             rc = instattn_bwd_ws_bf16(
                 bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                 spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
                 bf(grad_output), bf(grad_mask_output), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
                 bf(grad_value), grad_loc.data_ptr<float>(), grad_sw.data_ptr<float>(),
-                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, st);
+                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, 0, st);
     }
     check_rc(rc, "instattn_bwd");
     return {grad_value, grad_loc, grad_sw, grad_lw};

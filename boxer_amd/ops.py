@@ -92,10 +92,10 @@ class BackwardPlan:
     which the forward's launch already counted and scanned the sample points' destination bins (the
     binning only depends on the sampling locations), plus what it is valid for."""
 
-    __slots__ = ("buf", "key")
+    __slots__ = ("buf", "key", "hints")
 
-    def __init__(self, buf, key):
-        self.buf, self.key = buf, key
+    def __init__(self, buf, key, hints=0):
+        self.buf, self.key, self.hints = buf, key, hints       # hints: as the forward ran (BOXATTN_HINT_*)
 
 
 def _plan_key(dims, loc, weights):
@@ -113,19 +113,85 @@ def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
     return buf, sh, ls
 
 
-_STATE = {}          # (device index, stream handle) -> zeroed ticket buffer the library keeps zero
+_STATE = {}          # (device index, stream handle) -> the library's persistent per-stream state buffer
 
 
 def _state_buffer(device, stream, nbytes):
-    """The riders' ticket buffer (include/boxattn.h, *_fwd_train_*: `state`): zeroed once, one per stream --
-    calls on one stream never overlap and every call leaves it zero -- instead of a zero-fill launch in
-    front of every training forward."""
+    """The library's state buffer (include/boxattn.h, *_fwd_train_*: `state`): zeroed once, one per stream --
+    calls on one stream never overlap and every call leaves the tickets in it zero -- instead of a zero-fill
+    launch in front of every training forward; its tail holds the locality counters (_Locality)."""
     key = (device.index, stream)
     buf = _STATE.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(int(nbytes), 4096), dtype=torch.uint8, device=device)
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         _STATE[key] = buf
     return buf
+
+
+class _Locality:
+    """Data-driven choice between the window-staged and the row-gather kernels of the encoder case (VERDICT
+    round 3, item 7).  The staged forward adds {points that missed their window, points sampled} to counters
+    in the state buffer; after a training forward the counters are copied to pinned host memory WITHOUT a
+    synchronisation, and whichever copy has arrived by the next call decides its `hints`: above
+    MISS_THRESHOLD the calls run the gather kernels (BOXATTN_HINT_NOT_LOCAL); every PROBE_EVERY-th call runs
+    the staged kernels again to see whether the sampling locations have become local.  One instance per
+    (device, stream, dimensions); results never depend on the choice."""
+
+    MISS_THRESHOLD = 0.5
+    PROBE_EVERY = 64
+    enabled = True
+
+    def __init__(self):
+        self.not_local = False
+        self.calls_since_probe = 0
+        self.pending = None          # (event, pinned host tensor)
+        self.last = None             # counters at the previous read
+        self.ratio = None            # the miss ratio the current choice is based on
+
+    def hints(self):
+        if self.pending is not None and self.pending[0].query():
+            now = self.pending[1].clone().view(-1, 2).sum(0)
+            self.pending = None
+            if self.last is not None:
+                d_miss, d_all = int(now[0] - self.last[0]), int(now[1] - self.last[1])
+                if d_all > 0:
+                    self.ratio = d_miss / d_all
+                    self.not_local = self.ratio > self.MISS_THRESHOLD
+            self.last = now
+        if not self.enabled:
+            return 0
+        if self.not_local:
+            self.calls_since_probe += 1
+            if self.calls_since_probe >= self.PROBE_EVERY:
+                self.calls_since_probe = 0
+                return 0                                   # probe: a staged call refreshes the counters
+            return _lib.HINT_NOT_LOCAL
+        return 0
+
+    def after_call(self, state, hints):
+        """Queue an asynchronous read of the counters (staged calls only; one read in flight at a time)."""
+        if hints or self.pending is not None or torch.cuda.is_current_stream_capturing():
+            return
+        if self.last is None:        # first call on this stream / shape: counters before it are the baseline
+            self.last = torch.zeros(2, dtype=torch.int64)
+        host = torch.empty(128, dtype=torch.int64, pin_memory=True)
+        host.copy_(state[:1024].view(torch.int64), non_blocking=True)      # the counters: the buffer's first 1 KiB
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, host)
+
+
+_LOCALITY = {}       # (device index, stream handle, dims) -> _Locality
+
+
+def _locality(value, stream, dims):
+    # (only the window-staged kernels of bf16 box attention with one query per pixel collect the counters;
+    # everything else simply never sees a non-zero miss count)
+    key = (value.device.index, stream, tuple(dims), value.dtype)
+    loc = _LOCALITY.get(key)
+    if loc is None:
+        loc = _LOCALITY[key] = _Locality()
+    return loc
 
 
 def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
@@ -138,14 +204,18 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
         state = _state_buffer(value.device, stream, lib.boxattn_state_bytes(dims[0], dims[2]))
+        adapt = _locality(value, stream, dims)
+        hints = adapt.hints()
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, buf.data_ptr() if buf is not None else 0,
-                buf.numel() if buf is not None else 0, state.data_ptr(), state.numel(),
+                buf.numel() if buf is not None else 0, state.data_ptr(), state.numel(), hints,
                 ctypes.addressof(built), stream)
+        if rc == 0:
+            adapt.after_call(state, hints)
     if rc != 0:
         _STATE.pop((value.device.index, stream), None)      # (its tickets may not be zero any more)
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
-    return BackwardPlan(buf, _plan_key(dims, loc, weights)) if built.value else None
+    return BackwardPlan(buf, _plan_key(dims, loc, weights), hints) if built.value else None
 
 
 def workspace_bytes(value, shapes, lsi, dims):
@@ -167,7 +237,8 @@ def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args,
         stream = torch.cuda.current_stream(value.device).cuda_stream
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(),
-                plan.buf.data_ptr() if ready else 0, plan.buf.numel() if ready else 0, stream)
+                plan.buf.data_ptr() if ready else 0, plan.buf.numel() if ready else 0,
+                plan.hints if plan is not None else 0, stream)
     if rc != 0:
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
 

@@ -138,6 +138,7 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  *   plan / plan_bytes : NULL / 0 -- the call plans for itself (count + scan passes first) -- or the
  *       buffer a *_fwd_train_* call filled (*plan_built == 1) for the SAME sampling locations,
  *       dimensions and option settings; it is only read.
+ *   hints : 0, or BOXATTN_HINT_* bits (see *_fwd_train_*); speed only, never results.
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
  * B*S*H*C floats); a plan the backward cannot use (operands the fast paths reject) is ignored.
@@ -153,27 +154,27 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
                        void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes,
-                       void *stream);
+                       int hints, void *stream);
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, void *stream);
+                        const void *plan, size_t plan_bytes, int hints, void *stream);
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
                         const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, void *stream);
+                        const void *plan, size_t plan_bytes, int hints, void *stream);
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
                          const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         const void *plan, size_t plan_bytes, void *stream);
+                         const void *plan, size_t plan_bytes, int hints, void *stream);
 
 /*
  * ---- reference windows + box offsets -> sampling grid (opt-in; SURVEY.md 8(f) N1, first step) --
@@ -216,7 +217,17 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * the caller ZEROED ONCE and keeps for the calls it issues on THIS stream: the riders' hand-off tickets.
  * Every call leaves it zero again, and calls on one stream never overlap, so it is never cleared again.
  * Without it the tickets live in `plan` and a zero-fill launch (~5 us) precedes the forward kernel.
+ * The FIRST 1 KiB of the state buffer holds 64 pairs of uint64 counters (the tickets follow; one buffer serves
+ * calls of every shape on its stream)
+ * that the window-staged forward of the encoder case only ever ADDS to: {sample points it had to fetch from
+ * global memory because their footprint missed the staged window, sample points inside the window test}.  A
+ * caller may read them whenever it likes (e.g. an asynchronous copy after a call; deltas between two reads)
+ * and, when most points miss -- sampling locations that are not local to their query, e.g. uniformly random
+ * ones -- pass BOXATTN_HINT_NOT_LOCAL in `hints` of its next calls: forward and point gradients then run on
+ * the row-gather kernels (same results; measured 14.5 against 12.8 Gpts/s on uniformly random locations,
+ * 17 against 25 on BoxeR's).  boxer_amd.ops does exactly that.
  */
+#define BOXATTN_HINT_NOT_LOCAL 1
 size_t boxattn_state_bytes(int B, int H);
 size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                           const int64_t *shapes_host, const int64_t *lsi_host);
@@ -224,24 +235,24 @@ int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64
                           const float *loc, const float *attn, int B, int S, int H, int C, int L,
                           int Lq, int P, float *out, const int64_t *shapes_host,
                           const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                          size_t state_bytes, int *plan_built, void *stream);
+                          size_t state_bytes, int hints, int *plan_built, void *stream);
 int boxattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *attn, int B, int S, int H, int C, int L,
                            int Lq, int P, uint16_t *out, const int64_t *shapes_host,
                            const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                           size_t state_bytes, int *plan_built, void *stream);
+                           size_t state_bytes, int hints, int *plan_built, void *stream);
 int instattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                            const float *loc, const float *spatial_w, const float *level_w, int B,
                            int S, int H, int C, int L, int Lq, int P, float *out, float *mask_out,
                            const int64_t *shapes_host, const int64_t *lsi_host, void *plan,
-                           size_t plan_bytes, void *state, size_t state_bytes, int *plan_built,
+                           size_t plan_bytes, void *state, size_t state_bytes, int hints, int *plan_built,
                            void *stream);
 int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                             const float *loc, const float *spatial_w, const float *level_w, int B,
                             int S, int H, int C, int L, int Lq, int P, uint16_t *out,
                             uint16_t *mask_out, const int64_t *shapes_host,
                             const int64_t *lsi_host, void *plan, size_t plan_bytes, void *state,
-                            size_t state_bytes, int *plan_built, void *stream);
+                            size_t state_bytes, int hints, int *plan_built, void *stream);
 
 /*
  * Kernel-variant override for tests and A/B benchmarks (process-global, not thread-safe):

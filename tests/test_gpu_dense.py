@@ -259,3 +259,38 @@ def test_riders_match_the_stand_alone_passes(fwd):
             # (the order of the records inside a bin, hence the float32 summation order, may differ)
             assert err <= (1e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, ref[1].float().abs().max().item())
     lib.boxattn_set_option(OPT_DENSE_FWD, old_fwd)
+
+
+def test_kernel_choice_follows_the_data(monkeypatch, dense_switch):
+    """the staged forward counts the points that miss their windows; boxer_amd.ops reads
+    the counters without synchronising and asks for the row-gather kernels (BOXATTN_HINT_NOT_LOCAL) once most
+    points miss -- uniformly random locations -- and goes back to the staged kernels when a probe call finds the
+    locations local again.  The results never depend on the choice."""
+    from boxer_amd import ops
+    dense_switch(True)
+    monkeypatch.setattr(ops._Locality, "PROBE_EVERY", 3)
+    ops._LOCALITY.clear()
+    levels = [(64, 48), (32, 24), (16, 12), (8, 6)]          # big enough for the windows of most (tile, level) pairs
+    rand, local = make_case(levels, "test", seed=21), make_case(levels, "model", seed=22)
+
+    def steps(inp, n):
+        seen = []
+        for _ in range(n):
+            out, grads = run(inp)                      # forward_train + backward(plan): synchronises at the end
+            seen.append(next(iter(ops._LOCALITY.values())).not_local)
+            for name, worst, tol in bench.parity_report(inp, out, grads):
+                assert worst <= tol, (name, worst)
+        return seen
+
+    seen = steps(rand, 5)
+    assert len(ops._LOCALITY) == 1
+    state = next(iter(ops._LOCALITY.values()))
+    assert seen[0] is False and seen[-1] is True, seen          # decided from the first calls' counters
+    assert state.ratio is not None and state.ratio > 0.6, state.ratio
+    v, sh, ls, loc, attn = (rand[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
+    hinted = [ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)[1].hints for _ in range(6)]
+    torch.cuda.synchronize()
+    assert 1 in hinted and 0 in hinted                          # gather calls, with a staged probe in between
+    seen = steps(local, 8)                                      # same shape, local boxes now: a probe notices
+    assert seen[-1] is False, seen
+    assert state.ratio < 0.4, state.ratio
