@@ -190,6 +190,11 @@ def make_step(inp, entry="ops"):
                                                   "grad_out"))
     if entry == "function":
         import boxer_amd
+        # One tiny autograd graph per step: with the engine's worker threads every step pays a cross-thread
+        # hand-over (measured on the GPU box's host: 127 us per step for float32, 220 us for bfloat16, against
+        # 100 us on the calling thread -- tools/gpu_cpu_overhead.py), which a real training step pays once per
+        # ITERATION, not once per operator.  The bench therefore runs the backward on the calling thread.
+        torch.autograd.set_multithreading_enabled(False)
         bf16 = v.dtype == torch.bfloat16
         vg, lg, ag = (t.detach().clone().requires_grad_() for t in (v, loc, attn))
         if inp["kind"] == "box":

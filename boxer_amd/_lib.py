@@ -83,6 +83,7 @@ _GRID_SIGNATURES = {
     "boxattn_grid_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 5 + [_vp, _vp, _vp],
 }
 EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "boxattn_set_option",
+           "boxattn_options_epoch",
            "boxattn_set_debug_buffer",
            "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16", *sorted(_POINTWISE_SIGNATURES),
            "boxattn_fwd_grid_f32", "boxattn_fwd_grid_bf16", "boxattn_bwd_ws_grid_f32",
@@ -216,6 +217,7 @@ def load():
             fn.restype = _i
     lib.boxattn_set_option.argtypes = [_i, _i]
     lib.boxattn_set_option.restype = _i
+    lib.boxattn_options_epoch.restype = _i
     for name, args in list(_GRID_SIGNATURES.items()) + list(_POINTWISE_SIGNATURES.items()):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = _i
@@ -232,6 +234,12 @@ def load():
 
 def build_info():
     return load().boxattn_build_info().decode()
+
+
+def options_epoch():
+    """boxattn_options_epoch(): bumped by every set_variant / set_option call (ops.py caches the size queries
+    per epoch: the workspace layouts depend on some switches)."""
+    return load().boxattn_options_epoch()
 
 
 def set_variant(v):

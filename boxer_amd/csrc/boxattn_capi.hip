@@ -1279,7 +1279,14 @@ int boxattn_profile_end(double *ms_sum, int *launches)
     return 0;
 }
 
-int boxattn_set_variant(int variant) { return g_variant.exchange(variant); }
+std::atomic<int> g_epoch{0};
+int boxattn_options_epoch(void) { return g_epoch.load(std::memory_order_relaxed); }
+
+int boxattn_set_variant(int variant)
+{
+    g_epoch.fetch_add(1, std::memory_order_relaxed);
+    return g_variant.exchange(variant);
+}
 
 // debugging aid, not part of the documented ABI: a device buffer the window-staged point-gradient kernel fills
 // with per-wave time stamps in builds with BOXATTN_DENSE_DEBUG (nullptr: off)
@@ -1288,6 +1295,7 @@ void boxattn_set_debug_buffer(float *p) { g_dense_dbg.store(p); }
 int boxattn_set_option(int key, int value)
 {
     if (key < 0 || key >= kNumOpts || !opt_live(key)) return -1;
+    g_epoch.fetch_add(1, std::memory_order_relaxed);
     return g_opt[key].exchange(value);
 }
 

@@ -103,12 +103,19 @@ def _plan_key(dims, loc, weights):
                                                     for t in (loc,) + tuple(weights))
 
 
+_SIZES = {}          # (query name, is_bf16, dims, level tables) -> bytes: the size queries are pure functions
+
+
 def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
     """A scratch tensor of the size the library asks for (query: boxattn_plan_bytes /
     boxattn_bwd_workspace_bytes; None for 0 bytes when minimum is 0) + the host level tables."""
     sh, ls = _host_table(shapes), _host_table(lsi)
     is_bf16 = int(value.dtype == torch.bfloat16)
-    nbytes = max(int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)), minimum)
+    key = (query.__name__, is_bf16, dims, sh.tobytes(), ls.tobytes(), _lib.options_epoch())
+    nbytes = _SIZES.get(key)
+    if nbytes is None:
+        nbytes = _SIZES[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
+    nbytes = max(nbytes, minimum)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
     return buf, sh, ls
 
@@ -144,13 +151,18 @@ class _Locality:
     def __init__(self):
         self.not_local = False
         self.calls_since_probe = 0
-        self.pending = None          # (event, pinned host tensor)
+        self.pending = None          # a read of the counters is in flight
+        self.host = self.event = None    # pinned buffer / event of the reads
         self.last = None             # counters at the previous read
         self.ratio = None            # the miss ratio the current choice is based on
+        self.since_read = 0
+        self.reads = 0
+
+    READ_EVERY = 16                  # staged calls between two reads of the counters
 
     def hints(self):
-        if self.pending is not None and self.pending[0].query():
-            now = self.pending[1].clone().view(-1, 2).sum(0)
+        if self.pending is not None and self.event.query():
+            now = self.host.view(-1, 2).sum(0)
             self.pending = None
             if self.last is not None:
                 d_miss, d_all = int(now[0] - self.last[0]), int(now[1] - self.last[1])
@@ -164,21 +176,30 @@ class _Locality:
             self.calls_since_probe += 1
             if self.calls_since_probe >= self.PROBE_EVERY:
                 self.calls_since_probe = 0
+                self.since_read = self.READ_EVERY       # (a probe is always read)
                 return 0                                   # probe: a staged call refreshes the counters
             return _lib.HINT_NOT_LOCAL
         return 0
 
     def after_call(self, state, hints):
-        """Queue an asynchronous read of the counters (staged calls only; one read in flight at a time)."""
-        if hints or self.pending is not None or torch.cuda.is_current_stream_capturing():
+        """Queue an asynchronous read of the counters: after the first staged calls, then every READ_EVERY-th
+        one (one read in flight at a time; nothing here ever waits for the GPU)."""
+        if hints or self.pending is not None:
             return
-        if self.last is None:        # first call on this stream / shape: counters before it are the baseline
-            self.last = torch.zeros(2, dtype=torch.int64)
-        host = torch.empty(128, dtype=torch.int64, pin_memory=True)
-        host.copy_(state[:1024].view(torch.int64), non_blocking=True)      # the counters: the buffer's first 1 KiB
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending = (ev, host)
+        self.since_read += 1
+        if self.since_read < self.READ_EVERY and self.reads >= 2:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.host is None:
+            self.host = torch.empty(128, dtype=torch.int64, pin_memory=True)
+            self.event = torch.cuda.Event()
+            self.last = torch.zeros(2, dtype=torch.int64)      # counters before the first call: the baseline
+        self.host.copy_(state[:1024].view(torch.int64), non_blocking=True)   # the counters: the buffer's first 1 KiB
+        self.event.record()
+        self.pending = True
+        self.since_read = 0
+        self.reads += 1
 
 
 _LOCALITY = {}       # (device index, stream handle, dims) -> _Locality

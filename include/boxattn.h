@@ -355,6 +355,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      workgroups (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
  */
 int boxattn_set_option(int key, int value);
+/* Number of boxattn_set_variant / boxattn_set_option calls so far: lets a binding cache the size queries
+ * (boxattn_plan_bytes, boxattn_bwd_workspace_bytes: pure functions of their arguments and the switches). */
+int boxattn_options_epoch(void);
 
 /*
  * Debugging aid of the window-staged kernels: builds with -DBOXATTN_DENSE_DEBUG=2 write per-wave time

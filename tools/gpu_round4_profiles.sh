@@ -1,12 +1,14 @@
 #!/bin/bash
-# Round-3 checkpoint on the GPU box: smoke, bench lines, rocprofv3 kernel stats, HBM traffic (PMC,
-# separate passes), SQ instruction mix, workload matrix, A/B of this round's switches.  -> gpurun_out/r03/
-#   gpurun --timeout 2400 -- bash tools/gpu_round3_profiles.sh
-R=gpurun_out/r03; mkdir -p $R; export TMPDIR=/tmp
+# Round-4 checkpoint on the GPU box: smoke, bench lines (default, driver flags, function entry), the dtype x input
+# matrix, rocprofv3 kernel stats, HBM traffic (PMC, separate passes), SQ instruction mix, every workload, A/B of
+# this round's switches.  -> gpurun_out/r04/
+#   gpurun --timeout 2400 -- bash tools/gpu_round4_profiles.sh
+R=gpurun_out/r04; mkdir -p $R; export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > $R/gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 > $R/smoke.log
 timeout 600 python bench.py > $R/bench_default.json 2> $R/bench_default.err
 timeout 300 python bench.py --steps 20 --warmup 5 > $R/bench_driver_flags.json 2>> $R/bench_default.err
+timeout 300 python bench.py --entry function --no-cpu-baseline > $R/bench_function_entry.json 2>> $R/bench_default.err
 for dt in bf16 fp32; do for inp in model test; do
   timeout 300 python bench.py --steps 200 --warmup 20 --dtype $dt --inputs $inp --no-cpu-baseline 2>/dev/null | tail -1 >> $R/bench_matrix.log
 done; done
@@ -23,12 +25,13 @@ for cfg in "C2_bf16_model" "C2_fp32_model --dtype fp32" "C2_bf16_test --inputs t
 done
 bash tools/gpu_workloads.sh > $R/workloads.log 2>&1
 # instruction mix and wait states of every kernel of the step (three passes)
-bash tools/gpu_pmc_multi.sh r03sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
+bash tools/gpu_pmc_multi.sh r04sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
   "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
-  "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" > $R/pmc_sq.txt 2>&1
-rm -rf gpurun_out/pmc_r03sq_1 gpurun_out/pmc_r03sq_2 gpurun_out/pmc_r03sq_3
+  "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" > /dev/null 2>&1
+python tools/sq_summary.py gpurun_out/pmc_r04sq_1 gpurun_out/pmc_r04sq_2 gpurun_out/pmc_r04sq_3 > $R/pmc_sq.txt 2>&1
+rm -rf gpurun_out/pmc_r04sq_1 gpurun_out/pmc_r04sq_2 gpurun_out/pmc_r04sq_3
 # this round's switches, one at a time against the default (boxattn_set_option key=value)
-for o in "" "17=1" "11=1" "15=1" "16=1" "14=2" "17=1 --opt 11=1 --opt 16=1 --opt 15=1"; do
+for o in "" "15=1" "15=2" "20=273" "20=1041" "20=819" "17=1" "11=1" "17=1 --opt 11=1 --opt 15=1"; do
   for inp in model test; do
     echo -n "opt ${o:-default} inputs $inp : " >> $R/ab_switches.log
     timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --inputs $inp ${o:+--opt $o} 2>/dev/null | tail -1 | python -c "
