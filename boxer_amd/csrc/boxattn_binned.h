@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void bin_scan_a_kernel(int *__restrict__ part,
                                                          int *__restrict__ subtot, BinPlan plan)
 {
     const int sub = blockIdx.x, s = blockIdx.y;
-    const int wps = (n_wg + kScanSub - 1) / kScanSub;
+    const int wps = scan_wps(n_wg);
     const int w_lo = sub * wps, w_hi = min(n_wg, w_lo + wps);
     int *sp = part + (size_t)s * n_wg * plan.nblk;
     // grid.z covers the blocks 256 at a time (big maps: thousands of blocks per slice)
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
         const bool live = k < plan.nblk;
         int c = 0;
         if (live && fuse_wg > 0) {                 // workgroup counts -> first slots, both levels
-            const int wps = (fuse_wg + kScanSub - 1) / kScanSub;
+            const int wps = scan_wps(fuse_wg);
             int *sp = part + (size_t)s * fuse_wg * plan.nblk + k;
             for (int u = 0; u < kScanSub; ++u) {
                 subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_seg_kernel(int *__restr
     const bool live = k < plan.nblk;
     int c = 0;
     if (live && fuse_wg > 0) {
-        const int wps = (fuse_wg + kScanSub - 1) / kScanSub;
+        const int wps = scan_wps(fuse_wg);
         int *sp = part + (size_t)s * fuse_wg * plan.nblk + k;
         for (int u = 0; u < kScanSub; ++u) {
             subtot[((size_t)s * kScanSub + u) * plan.nblk + k] = c;

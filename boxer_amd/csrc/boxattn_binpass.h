@@ -87,11 +87,23 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
             }
         }
     };
+    // one record of point (u, k) into slot `slot` of its bin
+    auto put_record = [&](const Step &t, int u, int k, int slot) {
+        const int id = ((q0 + t.ql[u] * qstep) << plan.lp_bits) | (t.lp0[u] + k);
+        if constexpr (WIDE)
+            reinterpret_cast<int4 *>(rec)[slot] = make_int4(id, __float_as_int(t.xy[u][k].x),
+                                                            __float_as_int(t.xy[u][k].y), __float_as_int(t.wv[u][k]));
+        else
+            rec[slot] = id;
+    };
     auto work_step = [&](const Step &t, int g0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g0 + u * THREADS >= n_grp) break;
             const BinLevel lv = s_lv[(int)(((float)t.lp0[u] + 0.5f) * rcp_p)];   // level = lp / P
+            // (One LDS atomic per touched block and (query, level) GROUP -- adding how many of its four points have a
+            // record there -- instead of one per point and block was built and measured: the 2 x 2 block bookkeeping
+            // costs more vector instructions than the atomics it saves; a fat rider's count pass 21 -> 26 us.)
 #pragma unroll
             for (int k = 0; k < PT; ++k) {
                 int blk[4];
@@ -102,15 +114,7 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
                 for (int j = 0; j < 4; ++j) {
                     if (blk[j] >= 0) {
                         const int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
-                        if constexpr (FILL) {
-                            const int id = ((q0 + t.ql[u] * qstep) << plan.lp_bits) | (t.lp0[u] + k);
-                            if constexpr (WIDE)
-                                reinterpret_cast<int4 *>(rec)[slot] =
-                                    make_int4(id, __float_as_int(t.xy[u][k].x),
-                                              __float_as_int(t.xy[u][k].y), __float_as_int(t.wv[u][k]));
-                            else
-                                rec[slot] = id;
-                        }
+                        if constexpr (FILL) put_record(t, u, k, slot);
                     }
                 }
             }
@@ -126,7 +130,7 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
 #pragma unroll
         for (int k = 0; k < kMaxBinLevels; ++k) s_lv[k] = plan.lv[k];
     }
-    const int wps = (n_wg + kScanSub - 1) / kScanSub;                // as in the scan
+    const int wps = scan_wps(n_wg);                // as in the scan
     const int *mysub = subtot + ((size_t)s * kScanSub + wg / wps) * plan.nblk;
     for (int k = threadIdx.x; k < plan.nblk; k += THREADS)
         hist[k] = FILL ? mypart[k] + mysub[k] + offsets[(size_t)s * (plan.nblk + 1) + k] : 0;
@@ -165,7 +169,18 @@ struct BinRide {
     int H, Lq, P, q_per_wg, n_wg;
     int flavour;             // kRideWide | kRideInterleave | kRidePt4
     RideGrid grid;           // grid.n_riders == 0: no riders in this launch
+    unsigned long long *trace;   // builds with BOXATTN_RIDE_TRACE: 8 s_memrealtime stamps per rider (tools/gpu_ride_trace.py)
 };
+#ifndef BOXATTN_RIDE_TRACE
+#define BOXATTN_RIDE_TRACE 0
+#endif
+#define RIDE_STAMP(k_)                                                                              \
+    do {                                                                                            \
+        if (BOXATTN_RIDE_TRACE && r.trace && threadIdx.x == 0) {                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            r.trace[(size_t)id * 8 + (k_)] = __builtin_amdgcn_s_memrealtime();                      \
+        }                                                                                           \
+    } while (0)
 
 // LDS of a rider: [histogram: kRideMaxBlocks ints][level table][4 x 4 wave sums][flag]
 struct RideLds {
@@ -190,6 +205,7 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
 #define BOXATTN_TUNE_RIDE_PRIO 0
 #endif
     if (BOXATTN_TUNE_RIDE_PRIO) __builtin_amdgcn_s_setprio(BOXATTN_TUNE_RIDE_PRIO);
+    RIDE_STAMP(0);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
     const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;
@@ -200,19 +216,28 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
     else
         bin_pass_body<THREADS, 8, 4, false, false, 1>(m.hist, m.lv, r.loc, r.w_sp, plan, r.H, r.Lq, r.P, r.q_per_wg,
                                                      r.n_wg, inter, r.part, r.subtot, r.offsets, r.records, s, wg);
+    RIDE_STAMP(1);
     // publish my row of counts, then the chain of last arrivers
     int *mypart = r.part + ((size_t)s * r.n_wg + wg) * plan.nblk;
     for (int k = threadIdx.x; k < plan.nblk; k += THREADS) agent_store(mypart + k, m.hist[k]);
     stores_left();
-    const int wps = (r.n_wg + kScanSub - 1) / kScanSub, u = wg / wps;
+    const int wps = scan_wps(r.n_wg), u = wg / wps;
     const int n_in_sub = min(r.n_wg, (u + 1) * wps) - u * wps, n_sub = (r.n_wg + wps - 1) / wps;
     int *tk = r.tickets + (size_t)s * kRideTickets;
-    if (!last_arriver<THREADS>(tk + u, n_in_sub, m.flag)) return;       // workgroup-uniform
+    const bool last = last_arriver<THREADS>(tk + u, n_in_sub, m.flag);
+    RIDE_STAMP(2);
+    if (!last) return;       // workgroup-uniform
     scan_sub_body<THREADS>(r.part, r.subtot, plan, r.n_wg, s, u);
     stores_left();
-    if (!last_arriver<THREADS>(tk + kScanSub, n_sub, m.flag)) return;
+    RIDE_STAMP(3);
+    if (n_sub > 1) {
+        if (!last_arriver<THREADS>(tk + kScanSub, n_sub, m.flag)) return;
+    } else {
+        __syncthreads();                   // one sub-range: its last arriver is the slice's (every wave's totals have left)
+    }
     const ScanOut o{r.subtot, r.offsets, r.items, r.combos, r.n_items};
     scan_blocks_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum);
+    RIDE_STAMP(4);
 }
 
 // Fill rider `id` = (slice, bin workgroup); bin workgroup 0 of a slice also clears the slice's combine tickets.
@@ -221,6 +246,7 @@ __device__ __forceinline__ void bin_fill_ride(const BinRide r, unsigned id, int 
 {
     if (id >= r.grid.n_riders) return;
     if (BOXATTN_TUNE_RIDE_PRIO) __builtin_amdgcn_s_setprio(BOXATTN_TUNE_RIDE_PRIO);
+    RIDE_STAMP(5);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
     const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;
@@ -236,6 +262,8 @@ __device__ __forceinline__ void bin_fill_ride(const BinRide r, unsigned id, int 
     else      // 4-byte records: one point per thread keeps neighbouring lanes on neighbouring slots (18.9 against 23.0 us)
         bin_pass_body<THREADS, 8, 4, true, false, 1>(m.hist, m.lv, r.loc, r.w_sp, plan, r.H, r.Lq, r.P, r.q_per_wg,
                                                     r.n_wg, inter, r.part, r.subtot, r.offsets, r.records, s, wg);
+    if (BOXATTN_RIDE_TRACE) { stores_left(); __syncthreads(); }
+    RIDE_STAMP(6);
 }
 
 }  // namespace boxattn

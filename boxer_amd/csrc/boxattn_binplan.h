@@ -12,6 +12,8 @@ struct BinLevel {
     int nbx, nby;         // blocks along x / y
     int blk0;             // first block id of this level inside a slice
     unsigned mw, mh;      // floor(2^32 / W) + 1, floor(2^32 / H) + 1 (0 for sizes <= 1): blk_of()
+    unsigned mnx, mny;    // floor(2^32 / nbx) + 1, floor(2^32 / nby) + 1: divisions by the block counts in
+                          // pack_block_geo() (0: the host found the multiply-high inexact for this level -> divide)
 };
 
 // Blocks are a BALANCED partition of the map: block column c covers
@@ -27,6 +29,11 @@ __device__ __forceinline__ int blk_of(int x, int nb, unsigned magic)
 }
 // first coordinate of block c: ceil(c size / nb)
 __device__ __forceinline__ int blk_lo(int c, int size, int nb) { return (c * size + nb - 1) / nb; }
+// n / nb by multiply-high (the host checked every n the block geometry can ask for), or the division
+__device__ __forceinline__ int div_nb(int n, int nb, unsigned magic)
+{
+    return magic ? (int)__umulhi((unsigned)n, magic) : n / nb;
+}
 
 struct BinPlan {
     int L;

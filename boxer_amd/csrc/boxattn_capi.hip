@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -40,8 +41,8 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
        kOptAccF32 = 19,       // float32 box attention, C = 32: accumulate on v_mfma_f32_32x32x2_f32: 0 / 1 off (VALU list walk), 2 on
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
-                              // of 8 workgroups (s = 0: all in front); | (d + 1) << 8: 2048 >> d bin workgroups
-                              // in all (fewer, fatter riders); 0: defaults
+                              // of 8 workgroups (s = 0: all in front); | v << 8: 64 v bin workgroups (riders) in all;
+                              // 0: defaults
        kNumOpts = 21 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
@@ -58,16 +59,16 @@ inline bool opt_live(int k)
 #ifndef BOXATTN_RIDE_SHIFT_FILL
 #define BOXATTN_RIDE_SHIFT_FILL 0      // fill riders: in front of the point-gradient kernel's grid
 #endif
-#ifndef BOXATTN_BIN_WG_DIV
-#define BOXATTN_BIN_WG_DIV 2           // bin workgroups (= riders) in all: 1024 >> this = 256, one per CU: FEW, FAT riders
+#ifndef BOXATTN_BIN_WG_TARGET
+#define BOXATTN_BIN_WG_TARGET 256      // bin workgroups (= riders) in all, of 256 threads' worth: one per CU.  FEW, FAT riders
                                        // with the next step's locations always in flight cost a quarter of the chip's
-                                       // wave slots for ~10 us; 1024 thin ones cost all of them for as long (C2 bf16 step
+                                       // wave slots; 1024 thin ones cost all of them for as long (C2 bf16 step
                                        // 146 / 139 / 135 / 154 us with 1024 / 512 / 256 / 128 riders)
 #endif
-inline int bin_wg_div()
+inline long long bin_wg_target()
 {
-    const int v = (opt(kOptRideShift) >> 8) & 15;
-    return v > 0 ? v - 1 : BOXATTN_BIN_WG_DIV;
+    const int v = (opt(kOptRideShift) >> 8) & 31;       // 64 v riders
+    return v > 0 ? 64ll * v : BOXATTN_BIN_WG_TARGET;
 }
 inline unsigned ride_shift(bool fill)
 {
@@ -577,6 +578,23 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
             return false;
         p.lv[l].mw = wl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)wl + 1) : 0u;
         p.lv[l].mh = hl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)hl + 1) : 0u;
+        // pack_block_geo(): n / nbx and n / nby by multiply-high for every n it can ask for, checked (once per
+        // (range, divisor) pair of the process: make_plan runs on every call)
+        const auto nb_magic = [](long long nmax, int nb) -> unsigned {
+            if (nb <= 1 || nmax >= (1ll << 24)) return 0u;
+            static std::mutex mu;
+            static std::map<std::pair<long long, int>, unsigned> known;
+            std::lock_guard<std::mutex> g(mu);
+            const auto it = known.find({nmax, nb});
+            if (it != known.end()) return it->second;
+            unsigned m = (unsigned)((1ull << 32) / (unsigned long long)nb + 1);
+            for (long long n = 0; n <= nmax && m; ++n)
+                if ((unsigned)(((unsigned long long)n * m) >> 32) != (unsigned)(n / nb)) m = 0u;
+            known[{nmax, nb}] = m;
+            return m;
+        };
+        p.lv[l].mnx = nb_magic(std::max<long long>((long long)p.lv[l].nbx * p.lv[l].nby, (long long)p.lv[l].nbx * wl + p.lv[l].nbx), p.lv[l].nbx);
+        p.lv[l].mny = nb_magic((long long)p.lv[l].nby * hl + p.lv[l].nby, p.lv[l].nby);
         p.lv[l].blk0 = (int)blk0;
         blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
     }
@@ -610,6 +628,8 @@ inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPl
     return make_plan_blocks(d, sh, ls, p);
 }
 
+std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: time stamps (boxattn_set_debug_buffer)
+
 // The PLAN of a backward -- everything the binning knows before the records are written: per bin workgroup
 // and block the first slot, per block the first record, the work-item list -- is what a training forward
 // hands to its backward (a few hundred KB: 1.4 MB at BoxeR-R50 shapes).  The SCRATCH -- the records
@@ -626,7 +646,7 @@ inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
     PlanLayout w;
     // ~2048 workgroups of 256 threads' worth of bin workgroups
     // ... and at most kScanSub * kScanWgPerSub per slice (the scan's two levels)
-    const long long wg_target = std::max(16ll, (2048ll * 256 / kBinThreads) >> bin_wg_div());   // ~8 waves per SIMD over the chip
+    const long long wg_target = bin_wg_target();
     w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
     w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
                                           (kScanSub * kScanWgPerSub));
@@ -699,6 +719,7 @@ inline BinRide make_ride(const float *loc, const float *w_sp, const Dims &d, con
     r.flavour = flavour;
     r.grid.n_riders = (unsigned)(pl.n_wg * d.B * d.H);
     r.grid.shift = ride_shift(fill);
+    r.trace = (unsigned long long *)g_dense_dbg.load();      // (read only by builds with BOXATTN_RIDE_TRACE)
     return r;
 }
 
@@ -758,7 +779,6 @@ inline void launch_binning(int flavour, const float *loc, const float *w_sp, con
 }
 
 // ------------------------------------------------- window-staged encoder kernels (boxattn_dense.h)
-std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: per-wave time stamps (boxattn_set_debug_buffer)
 // Encoder case: one query per pixel of packed levels, bf16 storage, C = 32, 2x2 points, <= 4 levels.
 inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p)
 {

@@ -369,6 +369,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
         bin_fill_ride<256>(ride, role.id, reinterpret_cast<int *>(win_lds));
         return;
     }
+#ifdef BOXATTN_DEBUG_NO_TILES          // timing experiments only: the riders alone
+    return;
+#endif
 #if BOXATTN_DENSE_DEBUG == 2
     unsigned long long ts[12];
     int ts_n = 0;

@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
         bin_count_ride<256>(ride, role.id, reinterpret_cast<int *>(win_lds));
         return;
     }
+#ifdef BOXATTN_DEBUG_NO_TILES          // timing experiments only: the riders alone
+    return;
+#endif
     DenseHot<L> hot;
     DenseMap Q;
     DenseWin wrow[L];

@@ -27,15 +27,27 @@ namespace boxattn {
 //   bits 0-11 oy, 12-23 ox, 24-25 bh - 1, 26-28 bw - 1, 29-31 level   (maps < 4096 x 4096)
 __device__ __forceinline__ unsigned pack_block_geo(const BinLevel &lv, int level, int blk)
 {
-    const int by = (blk - lv.blk0) / lv.nbx, bx = (blk - lv.blk0) % lv.nbx;
-    const int oy = blk_lo(by, lv.H, lv.nby), ox = blk_lo(bx, lv.W, lv.nbx);
-    const int bh = blk_lo(by + 1, lv.H, lv.nby) - oy, bw = blk_lo(bx + 1, lv.W, lv.nbx) - ox;
+    // (five integer divisions per block were ~200 instructions each way: a third of the block scan, which sits
+    // on the critical path of the training forward's launch; multiply-high with host-checked magic numbers)
+    const int rel = blk - lv.blk0;
+    const int by = div_nb(rel, lv.nbx, lv.mnx), bx = rel - by * lv.nbx;
+    const int oy = div_nb(by * lv.H + lv.nby - 1, lv.nby, lv.mny), ox = div_nb(bx * lv.W + lv.nbx - 1, lv.nbx, lv.mnx);
+    const int bh = div_nb((by + 1) * lv.H + lv.nby - 1, lv.nby, lv.mny) - oy;
+    const int bw = div_nb((bx + 1) * lv.W + lv.nbx - 1, lv.nbx, lv.mnx) - ox;
     return (unsigned)oy | ((unsigned)ox << 12) | ((unsigned)(bh - 1) << 24) |
            ((unsigned)(bw - 1) << 26) | ((unsigned)level << 29);
 }
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // sub-ranges of bin workgroups per slice, workgroups per sub-range at most
 constexpr int kScanThreads = 1024;     // bin_scan_kernel: one workgroup per slice walks the blocks 1024 at a time
 constexpr int kRideTickets = kScanSub + 1;        // per slice: one ticket per sub-range + the slice's
+// Bin workgroups per sub-range.  Up to kScanWgPerSub bin workgroups per slice (the fat riders: 16) form ONE
+// sub-range: its last arriver reads all their rows itself and goes straight on to the block scan -- one
+// hand-off in the chain instead of two (each is a write-through store + a ticket round trip, ~3 us, on the
+// critical path of the training forward's launch).
+__host__ __device__ inline int scan_wps(int n_wg)
+{
+    return n_wg <= kScanWgPerSub ? (n_wg > 0 ? n_wg : 1) : (n_wg + kScanSub - 1) / kScanSub;
+}
 
 struct ScanOut {
     int *subtot, *offsets;
@@ -47,7 +59,7 @@ struct ScanOut {
 template <int THREADS>
 __device__ __forceinline__ void scan_sub_body(int *part, int *subtot, const BinPlan &plan, int n_wg, int s, int u)
 {
-    const int wps = (n_wg + kScanSub - 1) / kScanSub;          // <= kScanWgPerSub (host)
+    const int wps = scan_wps(n_wg);          // <= kScanWgPerSub (host)
     const int w_lo = u * wps, w_hi = min(n_wg, w_lo + wps);
     int *sp = part + (size_t)s * n_wg * plan.nblk;
     for (int k = threadIdx.x; k < plan.nblk; k += THREADS) {
@@ -72,11 +84,16 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
 {
     constexpr int PER = kScanThreads / THREADS, NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // consecutive blocks per thread: as few as the slice's blocks need (452 blocks at BoxeR-R50 shapes: two per
+    // thread, 226 threads at work instead of 113 -- this scan is a serial stretch on the forward launch's critical path)
+    const int per = (plan.nblk + THREADS - 1) / THREADS;
     int c[PER], nch[PER], sum[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int k = tid * PER + j;
+        const int k = tid * per + j;
         c[j] = 0;
+        nch[j] = 0;
+        if (j >= per) continue;
         if (k < plan.nblk) {                       // sub-range totals -> sub-range first slots
             int tv[kScanSub];
 #pragma unroll
@@ -118,8 +135,8 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int k = tid * PER + j;
-        if (k < plan.nblk) {
+        const int k = tid * per + j;
+        if (j < per && k < plan.nblk) {
             o.offsets[(size_t)s * (plan.nblk + 1) + k] = run[0];
             // (the level table in LDS -- the count pass left it there: a per-lane index into the kernel
             // argument would put a copy of the plan into scratch)

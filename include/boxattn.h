@@ -351,8 +351,8 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      and accumulation, 16-byte records): 0 / 1 off (default), 2 on.
  *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
  *  20  where the riders sit in their host kernel's grid: (s_count + 1) | (s_fill + 1) << 4 -- a group of 8
- *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | (d + 1) << 8: 1024 >> d bin
- *      workgroups (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
+ *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | v << 8: 64 v bin workgroups
+ *      (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
  */
 int boxattn_set_option(int key, int value);
 /* Number of boxattn_set_variant / boxattn_set_option calls so far: lets a binding cache the size queries
