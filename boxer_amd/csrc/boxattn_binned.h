@@ -64,8 +64,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(const float *__restric
                                                   int *__restrict__ part,
                                                   const int *__restrict__ subtot,
                                                   const int *__restrict__ offsets,
-                                                  int *__restrict__ records)
+                                                  int *__restrict__ records, int *__restrict__ ctickets)
 {
+    // fill pass: bin workgroup 0 of a slice clears the slice's combine tickets of the accumulate launch (chunk_finish)
+    if (FILL && ctickets && blockIdx.x == 0)
+        for (int k = threadIdx.x; k < plan.nblk; k += kBinThreads) ctickets[(size_t)blockIdx.y * plan.nblk + k] = 0;
     // part[slice][workgroup][block]: after the count pass the number of records this workgroup
     // has for the block; the scan turns it into the workgroup's first slot inside the block's bin.
     // grid = (n_wg, slices).  (Placing all workgroups of a slice on one XCD, so that the record

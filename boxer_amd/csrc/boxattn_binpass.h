@@ -227,16 +227,17 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
     const bool last = last_arriver<THREADS>(tk + u, n_in_sub, m.flag);
     RIDE_STAMP(2);
     if (!last) return;       // workgroup-uniform
-    scan_sub_body<THREADS>(r.part, r.subtot, plan, r.n_wg, s, u);
-    stores_left();
-    RIDE_STAMP(3);
-    if (n_sub > 1) {
-        if (!last_arriver<THREADS>(tk + kScanSub, n_sub, m.flag)) return;
-    } else {
-        __syncthreads();                   // one sub-range: its last arriver is the slice's (every wave's totals have left)
-    }
     const ScanOut o{r.subtot, r.offsets, r.items, r.combos, r.n_items};
-    scan_blocks_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum);
+    if (n_sub == 1) {        // one sub-range: its last arriver is the slice's, and does both scan stages in one pass
+        RIDE_STAMP(3);
+        scan_blocks_body<THREADS>(o, plan, m.lv, 1, s, m.wsum, r.part, r.n_wg);
+    } else {
+        scan_sub_body<THREADS>(r.part, r.subtot, plan, r.n_wg, s, u);
+        stores_left();
+        RIDE_STAMP(3);
+        if (!last_arriver<THREADS>(tk + kScanSub, n_sub, m.flag)) return;
+        scan_blocks_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum);
+    }
     RIDE_STAMP(4);
 }
 

@@ -727,7 +727,8 @@ inline BinRide make_ride(const float *loc, const float *w_sp, const Dims &d, con
 // host kernels that carry none): stages kBinCount | kBinScan | kBinFill.
 enum { kBinCount = 1, kBinScan = 2, kBinFill = 4 };
 inline void launch_binning(int flavour, const float *loc, const float *w_sp, const Dims &d, const BinPlan &plan,
-                           const PlanLayout &w, char *pbuf, int *records, hipStream_t st, int stages)
+                           const PlanLayout &w, char *pbuf, int *records, hipStream_t st, int stages,
+                           int *ctickets = nullptr)
 {
     constexpr int BW = 8, BH = 4;
     const int ns = d.B * d.H;
@@ -741,7 +742,7 @@ inline void launch_binning(int flavour, const float *loc, const float *w_sp, con
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);
 #define BOXATTN_BIN(FILL_, WIDE_, PT_)                                                              \
     hipLaunchKernelGGL((bin_kernel<BW, BH, FILL_, WIDE_, PT_>), bgrid, dim3(kBinThreads), bsh, st, loc, w_sp, \
-                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, inter, part, subtot, offsets, records)
+                       plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, inter, part, subtot, offsets, records, ctickets)
     if (stages & kBinCount) {
         if (pt4) BOXATTN_BIN(false, false, 4); else BOXATTN_BIN(false, false, 1);
     }
@@ -1002,10 +1003,12 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
                                       grad_sp, grad_lv, st, gs, nullptr, nullptr, dp);
     }
-    if (!filled) launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill);
-    // in-launch combine: the fill riders have cleared the blocks' tickets
+    // in-launch combine (chunk_finish): the fill pass -- riding or not -- clears the blocks' tickets
+    const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2;
+    if (!filled)
+        launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill,
+                       own_combine ? nullptr : (int *)(sbuf + sl.ctickets));
     ChunkCombine cc{};
-    const bool own_combine = !filled || opt(kOptRiders) == 2;
     if (!own_combine) cc = ChunkCombine{(int *)(sbuf + sl.ctickets), combos, plan.nblk, plan.pslot_cap};
     int rc = launch_accumulate<ST, G, INST>(acc, grad_out, grad_mask, loc, w_sp, w_lv, d, plan, offsets, items,
                                             n_items, records, grad_value, partials, cc, st);

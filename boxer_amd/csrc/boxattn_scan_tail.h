@@ -78,9 +78,13 @@ __device__ __forceinline__ void scan_sub_body(int *part, int *subtot, const BinP
 
 // The slice's block scan (bin_scan_kernel's work, nblk <= kScanThreads): a thread takes
 // kScanThreads / THREADS CONSECUTIVE blocks, so the one block scan runs over the threads' sums.
+// fuse_part != nullptr (one sub-range, fuse_wg <= kScanWgPerSub bin workgroups): the sub-range stage is done here as
+// well -- every thread reads the fuse_wg published counts of its blocks itself -- instead of in a pass of its own
+// with a hand-off in between: a round trip and a barrier less on the chain.
 template <int THREADS>
 __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan &plan, const BinLevel *lv_lds,
-                                                 int n_sub, int s, int *wsum /* 4 x THREADS / 64 ints of LDS */)
+                                                 int n_sub, int s, int *wsum /* 4 x THREADS / 64 ints of LDS */,
+                                                 int *fuse_part = nullptr, int fuse_wg = 0)
 {
     constexpr int PER = kScanThreads / THREADS, NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -94,7 +98,19 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
         c[j] = 0;
         nch[j] = 0;
         if (j >= per) continue;
-        if (k < plan.nblk) {                       // sub-range totals -> sub-range first slots
+        if (k < plan.nblk && fuse_part) {          // the bin workgroups' counts -> their first slots (in place)
+            int *sp = fuse_part + (size_t)s * fuse_wg * plan.nblk + k;
+            int tv[kScanWgPerSub];
+#pragma unroll
+            for (int w = 0; w < kScanWgPerSub; ++w)            // (published by the count riders: read past the L1)
+                tv[w] = w < fuse_wg ? agent_load(sp + (size_t)w * plan.nblk) : 0;
+#pragma unroll
+            for (int w = 0; w < kScanWgPerSub; ++w) {
+                if (w < fuse_wg) sp[(size_t)w * plan.nblk] = c[j];                 // for the NEXT launch (fill)
+                c[j] += tv[w];
+            }
+            o.subtot[(size_t)s * kScanSub * plan.nblk + k] = 0;                    // the one sub-range starts the bin
+        } else if (k < plan.nblk) {                // sub-range totals -> sub-range first slots
             int tv[kScanSub];
 #pragma unroll
             for (int uu = 0; uu < kScanSub; ++uu)

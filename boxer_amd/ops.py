@@ -103,6 +103,23 @@ def _plan_key(dims, loc, weights):
                                                     for t in (loc,) + tuple(weights))
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(device):
+    """torch.cuda.device(device) -- unless it is the current device already (the usual case: the context manager
+    costs several microseconds of a 55 us step)."""
+    return _NO_GUARD if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 _SIZES = {}          # (query name, is_bf16, dims, level tables) -> bytes: the size queries are pure functions
 
 
@@ -222,7 +239,7 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     buf, sh, ls = _sized_buffer(lib.boxattn_plan_bytes, value, shapes, lsi, dims, minimum=0)
     built = ctypes.c_int(0)
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
-    with torch.cuda.device(value.device):
+    with _device_guard(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
         state = _state_buffer(value.device, stream, lib.boxattn_state_bytes(dims[0], dims[2]))
         adapt = _locality(value, stream, dims)
@@ -248,14 +265,42 @@ def workspace_bytes(value, shapes, lsi, dims):
             int(lib.boxattn_bwd_workspace_bytes(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data)))
 
 
+_WORKSPACE = {}      # (device index, stream handle) -> the backward's scratch tensor (grown as needed)
+
+
+def _workspace(query, value, shapes, lsi, dims, stream):
+    """The backward's scratch (bin records, partial tiles: contents only live inside one call).  One tensor per
+    (device, stream), reused: calls on a stream never overlap, and a 0.3 GB torch.empty per backward was a tenth
+    of the host time of a training step."""
+    sh, ls = _host_table(shapes), _host_table(lsi)
+    is_bf16 = int(value.dtype == torch.bfloat16)
+    key = (query.__name__, is_bf16, dims, sh.tobytes(), ls.tobytes(), _lib.options_epoch())
+    nbytes = _SIZES.get(key)
+    if nbytes is None:
+        nbytes = _SIZES[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
+    nbytes = max(nbytes, 256)
+    wkey = (value.device.index, stream)
+    ws = _WORKSPACE.get(wkey)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WORKSPACE[wkey] = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+    return ws, sh, ls
+
+
+def release_workspaces():
+    """Drop the cached scratch / state tensors (they are re-created on demand)."""
+    _WORKSPACE.clear()
+    _STATE.clear()
+    _LOCALITY.clear()
+
+
 def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
     """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch (+ plan)."""
     lib = _lib.load()
     ready = plan is not None and plan.key == _plan_key(dims, loc, weights)
-    ws, sh, ls = _sized_buffer(lib.boxattn_bwd_workspace_bytes, value, shapes, lsi, dims)
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
-    with torch.cuda.device(value.device):
+    with _device_guard(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
+        ws, sh, ls = _workspace(lib.boxattn_bwd_workspace_bytes, value, shapes, lsi, dims, stream)
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(),
                 plan.buf.data_ptr() if ready else 0, plan.buf.numel() if ready else 0,
