@@ -252,8 +252,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
                     piece_hi = u32x4{s2[0], s3[0], s2[1], s3[1]};
                 }
                 const int c_lo = cb * 32 + 8 * kb, c_hi = cb * 32 + 16 + 8 * kb;
-                if (live && c_lo < C) *reinterpret_cast<u32x4 *>(dst + c_lo) = piece_lo;
-                if (live && c_hi < C) *reinterpret_cast<u32x4 *>(dst + c_hi) = piece_hi;
+#ifndef BOXATTN_TUNE_GV_NT
+#define BOXATTN_TUNE_GV_NT 0       // grad_value rows with non-temporal stores (nobody on the GPU reads them soon)
+#endif
+                if (BOXATTN_TUNE_GV_NT) {
+                    if (live && c_lo < C) __builtin_nontemporal_store(piece_lo, reinterpret_cast<u32x4 *>(dst + c_lo));
+                    if (live && c_hi < C) __builtin_nontemporal_store(piece_hi, reinterpret_cast<u32x4 *>(dst + c_hi));
+                } else {
+                    if (live && c_lo < C) *reinterpret_cast<u32x4 *>(dst + c_lo) = piece_lo;
+                    if (live && c_hi < C) *reinterpret_cast<u32x4 *>(dst + c_hi) = piece_hi;
+                }
             }
         } else {
             // a chunk: fp32 partial tile; the block's last chunk to finish sums them (chunk_finish)

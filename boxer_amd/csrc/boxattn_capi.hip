@@ -37,7 +37,8 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
        kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
        kOptRiders = 15,       // count / scan / fill / combine inside the forward, point-gradient and accumulate launches:
-                              // 0 default (on), 1 off (launches of their own), 2 on except the combine (its own launch)
+                              // 0 default (on; the combine inside the accumulate launch only for small problems), 1 off
+                              // (launches of their own), 2 on except the combine (its own launch), 3 on, combine inside
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
        kOptAccF32 = 19,       // float32 box attention, C = 32: accumulate on v_mfma_f32_32x32x2_f32: 0 / 1 off (VALU list walk), 2 on
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
@@ -1003,8 +1004,13 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
                                       grad_sp, grad_lv, st, gs, nullptr, nullptr, dp);
     }
-    // in-launch combine (chunk_finish): the fill pass -- riding or not -- clears the blocks' tickets
-    const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2;
+    // Chunked blocks: summed by their last chunk inside the accumulate launch (chunk_finish; the fill pass -- riding
+    // or not -- clears the blocks' tickets) where the step is a chain of short launches, i.e. few sample points;
+    // by combine_partials_kernel behind it for the encoder-sized problems -- every chunk item pays a write-through
+    // + ticket round trip (~6 us of its wave slot) for the hand-off, which at 2 600 chunk items is as much as the
+    // extra launch, and more at COCO-rect shapes (C2' bf16: accumulate 96 us against 82 + 9).
+    const bool small = (long long)d.Lq * d.L * d.P < 65536;
+    const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2 || (opt(kOptRiders) == 0 && !small);
     if (!filled)
         launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill,
                        own_combine ? nullptr : (int *)(sbuf + sl.ctickets));

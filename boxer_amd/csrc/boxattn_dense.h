@@ -457,10 +457,21 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
         const float4 o_a = *reinterpret_cast<const float4 *>(res_a + p * P);
         const float4 o_0 = *reinterpret_cast<const float4 *>(res_xy + p * P * 2);
         const float4 o_1 = *reinterpret_cast<const float4 *>(res_xy + p * P * 2 + 4);
-        *reinterpret_cast<float4 *>(grad_attn + pt0 + p * P) = o_a;
+#ifndef BOXATTN_TUNE_PG_NT
+#define BOXATTN_TUNE_PG_NT 1       // the point gradients leave with non-temporal stores: nobody on the GPU reads them soon, and
+#endif                             // the bin records the fill riders of this launch write should stay in the Infinity Cache
+        float4 *ga4 = reinterpret_cast<float4 *>(grad_attn + pt0 + p * P);
         float4 *gl = reinterpret_cast<float4 *>(grad_loc + 2 * (size_t)(pt0 + p * P));
-        gl[0] = o_0;
-        gl[1] = o_1;
+        if (BOXATTN_TUNE_PG_NT) {
+            typedef float pg_f32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(pg_f32x4{o_a.x, o_a.y, o_a.z, o_a.w}, reinterpret_cast<pg_f32x4 *>(ga4));
+            __builtin_nontemporal_store(pg_f32x4{o_0.x, o_0.y, o_0.z, o_0.w}, reinterpret_cast<pg_f32x4 *>(gl));
+            __builtin_nontemporal_store(pg_f32x4{o_1.x, o_1.y, o_1.z, o_1.w}, reinterpret_cast<pg_f32x4 *>(gl + 1));
+        } else {
+            *ga4 = o_a;
+            gl[0] = o_0;
+            gl[1] = o_1;
+        }
     }
 #if BOXATTN_DENSE_DEBUG == 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

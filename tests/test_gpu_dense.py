@@ -240,11 +240,11 @@ def test_riders_match_the_stand_alone_passes(fwd):
         inp = bench.make_inputs("C2", dtype, "cuda", family="model", batch=2, seed=1)
         v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
         res = {}
-        for mode in (1, 0):
+        for mode in (1, 0, 3):           # own launches | riders (combine: own launch at this size) | riders, combine inside
             old = lib.boxattn_set_option(OPT_RIDERS, mode)
             try:
                 outs = []
-                for it in range(60 if mode == 0 else 2):
+                for it in range(2 if mode == 1 else 60):
                     out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
                     gv, gl, ga = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
                     outs.append((out, gv, gl, ga))
@@ -253,7 +253,7 @@ def test_riders_match_the_stand_alone_passes(fwd):
             finally:
                 lib.boxattn_set_option(OPT_RIDERS, old)
         ref = res[1][0]
-        for out, gv, gl, ga in res[0]:
+        for out, gv, gl, ga in res[0] + res[3]:
             assert torch.equal(out, ref[0]) and torch.equal(gl, ref[2]) and torch.equal(ga, ref[3])
             err = (gv.float() - ref[1].float()).abs().max().item()
             # (the order of the records inside a bin, hence the float32 summation order, may differ)
