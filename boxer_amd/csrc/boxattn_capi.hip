@@ -811,7 +811,7 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
     // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
     // (r = W_l / W_lq); their points lie a quarter box (ref / 4 pixels of the query's level, i.e.
     // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further.
-    // The levels are staged coarsest first into the workgroup's kDenseSlots pixel slots; what does
+    // The levels are staged coarsest first into the workgroup's kDenseLdsBytes of LDS; what does
     // not fit (a coarse tile's window on a fine level) is not staged.
     const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
     const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
@@ -827,13 +827,10 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             w.ax = (int)std::lround(kDenseTile * rx * 65536.0f); w.bx = (int)std::floor((0.5f * rx - 0.5f - mx) * 65536.0f);
             w.ay = (int)std::lround(kDenseTile * ry * 65536.0f); w.by = (int)std::floor((0.5f * ry - 0.5f - my) * 65536.0f);
             if (rx > 8.0f || ry > 8.0f) { w.ax = w.ay = 0; }      // (not staged anyway; keeps tx * ax inside 31 bits)
-#ifndef BOXATTN_DENSE_PITCH_PAD
-#define BOXATTN_DENSE_PITCH_PAD 2
-#endif
-            const int pitch = cols + BOXATTN_DENSE_PITCH_PAD;   // slots of neighbouring rows start 2 bank groups apart
-            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && used + rows * pitch <= kDenseSlots - 1;   // (the last slot is the forward's zero row)
-            w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, pitch, used);
-            if (fits) used += rows * pitch;
+            const int need = rows * dense_win_pitch16(cols);       // in 16-byte units
+            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && 16 * (used + need) <= kDenseZeroOff;
+            w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, used);
+            if (fits) used += need;
         }
     }
     return true;

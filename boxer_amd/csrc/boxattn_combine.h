@@ -41,7 +41,7 @@ struct CombinePlan {
 // Sum the cb.z partial tiles of one chunked block (cb = {block geometry, first slot, chunks}) and store its
 // rows in the storage type.  One wavefront, lane = (pixel, channel half).  AGENT: the tiles were published
 // inside this launch (agent-scope loads, past the L1); else they come from an earlier launch.
-template <typename ST, int C, bool AGENT>
+template <typename ST, int C, bool AGENT, int DEPTH = 4>
 __device__ __forceinline__ void combine_block(const int4 cb, const float *__restrict__ partials, int pslot_cap,
                                               int lv_start, int lv_W, int S, int H,
                                               ST *__restrict__ grad_value, int s, int lane)
@@ -62,10 +62,10 @@ __device__ __forceinline__ void combine_block(const int4 cb, const float *__rest
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(tile0), 0, (unsigned)cb.z * (unsigned)(PB * C * 4), 0x00020000);
     const unsigned off0 = (unsigned)((mypix * C + half * CH) * 4);
-    for (int j0 = 0; j0 < cb.z; j0 += 4) {                  // 4 partial tiles in flight
-        float4 t[4][CH / 4];
+    for (int j0 = 0; j0 < cb.z; j0 += DEPTH) {              // DEPTH partial tiles in flight
+        float4 t[DEPTH][CH / 4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
             const unsigned off = off0 + (unsigned)min(j0 + u, cb.z - 1) * (unsigned)(PB * C * 4);
 #pragma unroll
             for (int c = 0; c < CH / 4; ++c) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void combine_block(const int4 cb, const float *__rest
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
             if (j0 + u < cb.z) {
 #pragma unroll
                 for (int c = 0; c < CH / 4; ++c) {
@@ -114,7 +114,8 @@ __device__ __forceinline__ void combine_partials_body(const int4 *__restrict__ c
 #pragma unroll
         for (int k = 1; k < kMaxBinLevels; ++k)
             if (k == level) { lv_start = plan.start[k]; lv_W = plan.W[k]; }
-        combine_block<ST, C, false>(cb, partials, plan.pslot_cap, lv_start, lv_W, S, H, grad_value, s, lane);
+        // (a launch of its own is all latency -- the heaviest block's tiles in ONE round trip where the registers allow)
+        combine_block<ST, C, false, (C <= 32 ? 8 : 4)>(cb, partials, plan.pslot_cap, lv_start, lv_W, S, H, grad_value, s, lane);
     }
 }
 

@@ -37,8 +37,11 @@ namespace boxattn {
 #ifndef BOXATTN_DENSE_DEBUG
 #define BOXATTN_DENSE_DEBUG 0     // 2: s_memtime stamps of every wave (tools/gpu_dense_trace.py, DensePlan::dbg)
 #endif
+#ifndef BOXATTN_TUNE_PG_ROWS
+#define BOXATTN_TUNE_PG_ROWS 2    // corner rows a lane has in flight from LDS (2: 8 reads, 32 registers)
+#endif
 #ifndef BOXATTN_DENSE_WPE
-#define BOXATTN_DENSE_WPE 4       // waves per SIMD the register allocation aims at (LDS allows 4 workgroups per CU)
+#define BOXATTN_DENSE_WPE 5       // waves per SIMD the register allocation aims at (96 registers; 26 / 30 KB of LDS: 5 workgroups per CU)
 #endif
 typedef unsigned int dense_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -137,24 +140,26 @@ __device__ __forceinline__ DenseTileId dense_tile_of_block(const DensePlan &pl, 
 }
 
 // Placement of a tile's windows (wave-uniform) and the cooperative fetch: wave w takes the window rows
-// w, w + 4, ... of every level; a row of up to 16 pixels x 64 bytes is one load instruction (4 lanes
-// per pixel).  Returns with the rows in LDS and the workgroup past its barrier.
+// w, w + 4, ... of every level; a row of up to 16 pixels x 64 bytes is ONE direct-to-LDS load (4 lanes per
+// pixel; the lanes of pixels past the window's last column are switched off and write nothing).  The data
+// never passes through registers: round 3 staged through 64 VGPRs and a second pass of ds_write_b128,
+// which held the kernels at 4 waves per SIMD.  The rows have landed after s_waitcnt vmcnt(0) in every
+// wave + the workgroup's barrier (dense_stage_wait).
 struct DenseWinPos {
     unsigned geo;            // DenseWin::geo
     int x0, y0;
     __device__ __forceinline__ int rows() const { return (int)(geo & 31u); }
     __device__ __forceinline__ int cols() const { return (int)((geo >> 5) & 31u); }
-    __device__ __forceinline__ int pitch() const { return (int)((geo >> 10) & 63u); }
-    __device__ __forceinline__ int off() const { return (int)(geo >> 16); }
+    __device__ __forceinline__ int pitchb() const { return (int)((geo >> 10) & 127u) * 16; }     // bytes per window row
+    __device__ __forceinline__ int offb() const { return (int)(geo >> 17) * 16; }               // first byte
 };
 
-template <int L> struct DenseStageRegs { dense_u32x4 reg[L][kDenseWinMax / 4]; };
+typedef __attribute__((address_space(3))) void dense_lds_void;
 
 template <int L>
 __device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const DenseWin (&wrow)[L],
                                                   const DenseTileId &t, int lane, int wv,
-                                                  __amdgpu_buffer_rsrc_t rs, DenseWinPos (&win)[L],
-                                                  DenseStageRegs<L> &st)
+                                                  __amdgpu_buffer_rsrc_t rs, unsigned char *lds, DenseWinPos (&win)[L])
 {
     constexpr int C = 32, RPW = kDenseWinMax / 4;              // rows per wave and level at most
     const int j = lane >> 2, chunk = lane & 3;
@@ -176,35 +181,24 @@ __device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const 
         // corner row that counts lies inside the map; they are simply not fetched)
         const int rows = min(o.rows(), T.H - o.y0);
         unsigned soff = (unsigned)(o.y0 + wv) * row_bytes;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            if (wv + 4 * k < rows)                                     // wave-uniform
-                st.reg[l][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-            soff += 4u * row_bytes;
-        }
-    }
-}
-
-template <int L>
-__device__ __forceinline__ void dense_stage_commit(int lane, int wv, unsigned char *lds, const DenseMap (&maps)[L],
-                                                   const DenseWinPos (&win)[L], const DenseStageRegs<L> &st)
-{
-    constexpr int RPW = kDenseWinMax / 4;
-    const int j = lane >> 2, chunk = lane & 3;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const DenseWinPos &o = win[l];
-        const int rows = min(o.rows(), maps[l].H - o.y0);
-        const int step = __mul24(o.pitch(), 4 * kDenseSlotBytes);
-        unsigned char *dst = lds + __mul24(o.off() + j + wv * o.pitch(), kDenseSlotBytes) + chunk * 16;
+        int dst = o.offb() + wv * o.pitchb();                       // wave-uniform: it becomes M0
+        const int step = 4 * o.pitchb();
         if (j < o.cols()) {
 #pragma unroll
             for (int k = 0; k < RPW; ++k) {
-                if (wv + 4 * k < rows) *reinterpret_cast<dense_u32x4 *>(dst) = st.reg[l][k];
+                if (wv + 4 * k < rows)                                 // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dense_lds_void *)(lds + dst), 16, voff, soff, 0, 0);
+                soff += 4u * row_bytes;
                 dst += step;
             }
         }
     }
+}
+// every wave's rows have landed, and everybody knows
+__device__ __forceinline__ void dense_stage_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 __device__ __forceinline__ unsigned quad_bcast_u32(unsigned v, int t)      // t is a constant after unrolling
@@ -271,16 +265,17 @@ __device__ __forceinline__ void dense_corner_sums(const DensePoint &s, const Den
     const bool slow = act && d < 0, fast = act && d >= 0;
     if (__builtin_amdgcn_ballot_w64(fast) != 0ull) {               // wave-uniform: somebody reads the window
         // (lanes that do not: clamped slots, results masked or overwritten below)
-        const int pitchb = __mul24(o.pitch(), kDenseSlotBytes), offb = __mul24(o.off(), kDenseSlotBytes);
+        const int pitchb = o.pitchb(), offb = o.offb();
         const int rr0 = min(max(s.y0 - o.y0, 0), rows - 1), rr1 = min(max(s.y0 + 1 - o.y0, 0), rows - 1);
         const int cc0 = min(max(s.x0 - o.x0, 0), cols - 1), cc1 = min(max(s.x0 + 1 - o.x0, 0), cols - 1);
         const int rowb0 = offb + __mul24(rr0, pitchb), rowb1 = offb + __mul24(rr1, pitchb);
-        const int colb0 = __mul24(cc0, kDenseSlotBytes), colb1 = __mul24(cc1, kDenseSlotBytes);
+        const int colb0 = cc0 * kDenseSlotBytes, colb1 = cc1 * kDenseSlotBytes;
         const int slot[4] = {rowb0 + colb0, rowb0 + colb1, rowb1 + colb0, rowb1 + colb1};
         // two corners at a time: 8 LDS reads in flight, then the 32 dot products; the rows of corners
         // that do not count are read from a clamped slot and masked out bitwise -- a select on the
         // finished sum lets the compiler put every corner under its own branch (reads, wait, dots, four
         // times in a row), a multiplication by 0 would let a non-finite value of an unrelated pixel through
+#if BOXATTN_TUNE_PG_ROWS == 2
 #pragma unroll
         for (int k0 = 0; k0 < 4; k0 += 2) {
             unsigned va[16], vb[16];
@@ -290,6 +285,14 @@ __device__ __forceinline__ void dense_corner_sums(const DensePoint &s, const Den
             sk[k0] = __uint_as_float(__float_as_uint(da) & m[k0]);
             sk[k0 + 1] = __uint_as_float(__float_as_uint(db) & m[k0 + 1]);
         }
+#else
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned va[16];
+            dense_load_row(lds + slot[k], va);
+            sk[k] = __uint_as_float(__float_as_uint(dense_dot_row(gw, va)) & m[k]);
+        }
+#endif
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) sk[k] = 0.f;
@@ -355,7 +358,10 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     DensePlan pl, unsigned value_bytes, BinRide ride)
 {
     constexpr int C = 32, P = 4, LP = L * P;
-    __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
+#ifndef BOXATTN_TUNE_PG_STASH
+#define BOXATTN_TUNE_PG_STASH 1    // a lane parks its L attention weights in LDS until it needs them (4 registers)
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseLdsBytes + (BOXATTN_TUNE_PG_STASH ? 256 * 16 : 0)];
     static_assert(4 * kDenseResFloats * sizeof(float) <= sizeof(win_lds), "the result tiles reuse the window buffer");
     static_assert(kRideLdsInts * sizeof(int) <= sizeof(win_lds), "so do the riders");
     // (the wave index as a scalar: everything per window row -- row index, clamps, byte offsets, the
@@ -403,14 +409,15 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     // the window rows first: they are what the workgroup's barrier waits for; the lane's own inputs
     // (locations, weights, grad_out row) are requested behind them and land while the rows are staged
     DenseWinPos win[L];
-    DenseStageRegs<L> stage;
     DENSE_STAMP();                                                 // tile decoded
-    dense_stage_issue<L>(hot, wrow, t, lane, wv, rs, win, stage);
+    dense_stage_issue<L>(hot, wrow, t, lane, wv, rs, win_lds, win);
     DENSE_STAMP();                                                 // window rows requested
     float2 xy[L];
     float a[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+        // (plain loads: the training forward read these lines a launch ago and most are still in the Infinity
+        // Cache -- with non-temporal loads here and in the fill riders the launch took 81 us instead of 51)
         xy[l] = loc2[pt0 + l * P + p];
         a[l] = attn[pt0 + l * P + p];
     }
@@ -421,8 +428,15 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DENSE_STAMP();                                                 // everything has arrived
 #endif
-    dense_stage_commit<L>(lane, wv, win_lds, hot.lv, win, stage);
-    __syncthreads();                       // windows complete
+    // (the attention weights are needed last, for the location gradients: parked in a lane-private piece of LDS
+    // meanwhile -- held in registers the kernel does not fit five waves per SIMD, and the compiler's own spill
+    // goes to scratch with a full memory wait per value)
+    volatile float *a_stash = reinterpret_cast<volatile float *>(win_lds + kDenseLdsBytes) + 4 * threadIdx.x;
+    if (BOXATTN_TUNE_PG_STASH) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) a_stash[l] = a[l];
+    }
+    dense_stage_wait();                    // windows complete
     DENSE_STAMP();
 
     float ga[L], gx[L], gy[L];
@@ -434,11 +448,15 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
         dense_corner_sums(s, T, win[l], win_lds, gw, value, t.b * (unsigned)hot.S + (unsigned)T.start, H, h, vq, p, sk);
         const float w1 = s.hh * s.hw, w2 = s.hh * s.lw, w3 = s.lh * s.hw, w4 = s.lh * s.lw;
         const float gs_ = w1 * sk[0] + w2 * sk[1] + w3 * sk[2] + w4 * sk[3];
-        const float gx_ = (float)T.W * a[l] * (s.hh * (sk[1] - sk[0]) + s.lh * (sk[3] - sk[2]));
-        const float gy_ = (float)T.H * a[l] * (s.hw * (sk[2] - sk[0]) + s.lw * (sk[3] - sk[1]));
+        const float al = BOXATTN_TUNE_PG_STASH ? a_stash[l] : a[l];
+        const float gx_ = (float)T.W * al * (s.hh * (sk[1] - sk[0]) + s.lh * (sk[3] - sk[2]));
+        const float gy_ = (float)T.H * al * (s.hw * (sk[2] - sk[0]) + s.lw * (sk[3] - sk[1]));
         ga[l] = s.inside ? gs_ : 0.f;
         gx[l] = s.inside ? gx_ : 0.f;
         gy[l] = s.inside ? gy_ : 0.f;
+        // (finished HERE: left alone the compiler postpones this arithmetic to the epilogue and carries nine
+        // values per level -- corner sums and weights -- instead of three)
+        asm volatile("" : "+v"(ga[l]), "+v"(gx[l]), "+v"(gy[l]));
     }
     DENSE_STAMP();
     // ---- results: lane (q, p) holds its point on every level; memory wants, per (query, head),

@@ -51,8 +51,6 @@ __device__ __forceinline__ unsigned quad_evenodd_u32(unsigned v, int u)
 typedef short fwd_i16x4 __attribute__((ext_vector_type(4)));
 typedef float fwd_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDenseZeroSlot = kDenseSlots - 1;        // a 64-byte row of zeros (make_dense_plan leaves it free)
-
 template <int L>
 __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     const bf16_t *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attn,
@@ -61,8 +59,8 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
 {
     constexpr int C = 32, P = 4, LP = L * P;
     constexpr int kBias = 4096;                         // keeps the packed slot offset non-negative
-    constexpr int kZeroOff = kDenseZeroSlot * kDenseSlotBytes;
-    __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseSlots * kDenseSlotBytes];
+    constexpr int kZeroOff = kDenseZeroOff;
+    __shared__ __attribute__((aligned(16))) unsigned char win_lds[kDenseLdsBytes];
     const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // training forward: the backward's count pass and the scans chained behind it ride in this launch
     // (boxattn_ride.h, bin_count_ride)
@@ -92,8 +90,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(value), 0, value_bytes, 0x00020000);
     DenseWinPos win[L];
-    DenseStageRegs<L> stage;
-    dense_stage_issue<L>(hot, wrow, t, lane, wv, rs, win, stage);
+    dense_stage_issue<L>(hot, wrow, t, lane, wv, rs, win_lds, win);
     float2 xy[L];
     float a[L];
 #pragma unroll
@@ -103,8 +100,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     }
     if (threadIdx.x < 4)
         *reinterpret_cast<dense_u32x4 *>(win_lds + kZeroOff + 16 * threadIdx.x) = dense_u32x4{0u, 0u, 0u, 0u};
-    dense_stage_commit<L>(lane, wv, win_lds, hot.lv, win, stage);
-    __syncthreads();                                               // windows complete
+    dense_stage_wait();                                            // windows complete
 
     // supplier role inside the 16-lane group: the row of corner jc for the query of quad qs
     const int jc = (lane >> 2) & 3, qs = lane & 3;
@@ -130,7 +126,7 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
         const int d = min(min(ra - o.y0, o.y0 + rows - 1 - rb), min(ca - o.x0, o.x0 + cols - 1 - cb));
         const bool act = vq && s.inside;
         const bool fast = act && d >= 0, slow = act && d < 0;
-        const int pitchb = __mul24(o.pitch(), kDenseSlotBytes), offb = __mul24(o.off(), kDenseSlotBytes);
+        const int pitchb = o.pitchb(), offb = o.offb();
         const int slot0 = offb + __mul24(s.y0 - o.y0, pitchb) + __mul24(s.x0 - o.x0, kDenseSlotBytes) + kBias;
         const unsigned pack = fast ? ((unsigned)slot0 | (bits << 20)) : 0u;
         // the four corner weights x attention weight; for the matrix cores as hi + lo bf16 terms

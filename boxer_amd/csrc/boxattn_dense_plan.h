@@ -14,12 +14,18 @@ constexpr int kDenseMaxLevels = 4;
 constexpr int kDenseTile = 8;              // queries per tile side: one workgroup = 8x8 queries x one head
 constexpr int kDenseSub = 4;               // ... = 2x2 sub-tiles of 4x4 queries, one wavefront each
 constexpr int kDenseWinMax = 16;           // window rows / columns at most (one wave-load per window row)
-constexpr int kDenseSlotBytes = 80;        // one staged pixel: 64 bytes of bf16 channels + 16 bytes of padding
-                                           // (bank = 20 slot + 4 chunk mod 64: 16 consecutive slots, 16 bank groups)
-#ifndef BOXATTN_DENSE_SLOTS
-#define BOXATTN_DENSE_SLOTS 480
+// The windows in LDS.  A window row is written by ONE direct-to-LDS load (buffer_load_dwordx4 ... lds: 4 lanes
+// per pixel, destination = a wave-uniform base + lane x 16 bytes), so its pixels are 64 bytes apart with no
+// padding between them; consecutive ROWS are skewed by 16 bytes instead.  A pixel's 16-byte pieces then fall
+// into bank group (4 column + row + piece) mod 16: the 2x2 footprint of a point and the pixels of neighbouring
+// lanes spread over the 16 groups as well as a padded slot would, at 4/5 of the bytes.
+constexpr int kDenseSlotBytes = 64;        // one staged pixel: 32 bf16 channels
+constexpr int kDenseRowSkew = 16;          // bytes between the end of a window row and the start of the next
+#ifndef BOXATTN_DENSE_LDS
+#define BOXATTN_DENSE_LDS 26624
 #endif
-constexpr int kDenseSlots = BOXATTN_DENSE_SLOTS;   // staged pixels per workgroup (480: 38 400 bytes)
+constexpr int kDenseLdsBytes = BOXATTN_DENSE_LDS;  // per workgroup (26 KB: six workgroups per CU; BoxeR-R50 tiles need 25.4)
+constexpr int kDenseZeroOff = kDenseLdsBytes - kDenseSlotBytes;    // the forward's row of zeros (make_dense_plan leaves it free)
 constexpr int kDenseStatSlots = 64;        // pairs of 64-bit locality counters in the caller's state buffer (power of two)
 
 struct DenseLevel {
@@ -30,14 +36,15 @@ struct DenseLevel {
 };
 // window of level l for a tile of level lq: first column floor(tx * ax + bx) (tx = tile column),
 // first row floor(ty * ay + by), clamped into the map; rows == 0: not staged (global path only).
-// Staged pixel (r, c) of the window lives in slot off + r * pitch + c.
+// Staged pixel (r, c) of the window lives at byte 16 (off16 + r * pitch16) + 64 c of the workgroup's LDS.
 struct DenseWin {
     int ax, bx, ay, by;      // 16.16 fixed point: first column (tx * ax + bx) >> 16, first row alike
-    unsigned geo;            // rows | cols << 5 | pitch << 10 | off << 16 (one scalar register, see dense_win_*)
+    unsigned geo;            // rows | cols << 5 | pitch16 << 10 | off16 << 17 (one scalar register, see DenseWinPos)
 };
-inline unsigned dense_win_pack(int rows, int cols, int pitch, int off)
+inline int dense_win_pitch16(int cols) { return (cols * kDenseSlotBytes + kDenseRowSkew) / 16; }
+inline unsigned dense_win_pack(int rows, int cols, int off16)
 {
-    return (unsigned)rows | ((unsigned)cols << 5) | ((unsigned)pitch << 10) | ((unsigned)off << 16);
+    return (unsigned)rows | ((unsigned)cols << 5) | ((unsigned)dense_win_pitch16(cols) << 10) | ((unsigned)off16 << 17);
 }
 struct DensePlan {
     int L, B, Lq, S, H;

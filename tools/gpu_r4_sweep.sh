@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B sweep of the rider geometry (boxattn_set_option(20): placement shifts | rider count) and the chunk size.
-#   gpurun --timeout 1500 -- bash tools/gpu_r4_sweep.sh
+# A/B sweep of the rider count (boxattn_set_option(20) = shifts | 64 v riders << 8) and the chunk size.
+#   gpurun --timeout 1500 -- bash tools/gpu_r4_sweep.sh            (BOXATTN_HIP_LIB selects a build variant)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 run() {  # dtype, extra args...
@@ -14,13 +14,11 @@ except Exception as e: print('bench failed', sys.argv[1:], e)
 " "$@"
 }
 : > gpurun_out/r4_sweep.log
-for d in 1 2 3 4; do for sc in 1 2 3; do for sf in 1 2 3; do
-  [ $sc != $sf ] && [ $sc != 1 ] && continue
-  v=$(( sc | (sf << 4) | (d << 8) ))
-  run bf16 --opt 20=$v | tee -a gpurun_out/r4_sweep.log
-done; done; done
-for c in 512 256 128; do
-  run bf16 --opt 20=785 --opt 10=$c | tee -a gpurun_out/r4_sweep.log    # 785 = 1 | 1<<4 | 3<<8
+for v in 3 4 5 6 8 10 16; do
+  run bf16 --opt 20=$(( 1 | (1 << 4) | (v << 8) )) | tee -a gpurun_out/r4_sweep.log
 done
-run fp32 --opt 20=785 | tee -a gpurun_out/r4_sweep.log
-run fp32 --opt 20=529 | tee -a gpurun_out/r4_sweep.log
+for c in 2048 1536 768; do
+  run bf16 --opt 10=$c | tee -a gpurun_out/r4_sweep.log
+done
+run bf16 --opt 15=3 | tee -a gpurun_out/r4_sweep.log
+run fp32 | tee -a gpurun_out/r4_sweep.log
