@@ -500,7 +500,7 @@ int launch_bwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
 
 
 // ------------------------------------------------------- binned backward (boxattn_binned.h)
-constexpr int kChunk = 1024;   // records per work item (upper bound)
+constexpr int kChunk = 1024, kChunkBig = 1536;   // records per work item (upper bound of the rule below; what it uses beyond)
 // Records per work item.  One wavefront works an item off 64 records a round, and a round is a
 // chain of dependent latencies (~3-5 us), so the kernel lasts at least rounds-per-item rounds:
 // with few sample points (the decoders: 300 queries) 1 024-record items leave a handful of waves
@@ -512,7 +512,9 @@ inline int bin_chunk(const Dims &d)
     if (forced > 0) return std::min(4096, std::max(64, (forced + 63) / 64 * 64));
     const long long rec_est = 3ll * d.Lq * d.L * d.P / 2;          // ~1.4 records per point
     const long long c = (rec_est / 256 + 63) / 64 * 64;
-    return (int)std::min<long long>(kChunk, std::max<long long>(128, c));
+    // (encoder-sized problems: 1 536 -- fewer partial tiles for the combine step, measured at C2 / C2' against
+    // 1 024 / 1 280 / 2 048: profiles/r04_chunk_sweep.log)
+    return c >= kChunk ? kChunkBig : (int)std::max<long long>(128, c);
 }
 
 // Which accumulate kernel a call runs, and with it the record format of the bin passes:

@@ -286,11 +286,13 @@ def test_kernel_choice_follows_the_data(monkeypatch, dense_switch):
     assert len(ops._LOCALITY) == 1
     state = next(iter(ops._LOCALITY.values()))
     assert seen[0] is False and seen[-1] is True, seen          # decided from the first calls' counters
-    assert state.ratio is not None and state.ratio > 0.6, state.ratio
+    # (the counters come from one tile in 61: on maps this small the ratio is a coarse sample -- only its side of
+    # the threshold is asserted)
+    assert state.ratio is not None and state.ratio > ops._Locality.MISS_THRESHOLD, state.ratio
     v, sh, ls, loc, attn = (rand[k] for k in ("value", "shapes", "lsi", "loc", "attn"))
     hinted = [ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)[1].hints for _ in range(6)]
     torch.cuda.synchronize()
     assert 1 in hinted and 0 in hinted                          # gather calls, with a staged probe in between
     seen = steps(local, 8)                                      # same shape, local boxes now: a probe notices
     assert seen[-1] is False, seen
-    assert state.ratio < 0.4, state.ratio
+    assert state.ratio < ops._Locality.MISS_THRESHOLD, state.ratio

@@ -31,7 +31,8 @@ bash tools/gpu_pmc_multi.sh r04sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_
 python tools/sq_summary.py gpurun_out/pmc_r04sq_1 gpurun_out/pmc_r04sq_2 gpurun_out/pmc_r04sq_3 > $R/pmc_sq.txt 2>&1
 rm -rf gpurun_out/pmc_r04sq_1 gpurun_out/pmc_r04sq_2 gpurun_out/pmc_r04sq_3
 # this round's switches, one at a time against the default (boxattn_set_option key=value)
-for o in "" "15=1" "15=2" "20=273" "20=1041" "20=819" "17=1" "11=1" "17=1 --opt 11=1 --opt 15=1"; do
+# (20 = (count shift + 1) | (fill shift + 1) << 4 | riders / 64 << 8: 2065 = 512 riders in front, 1058 = 256 interleaved 1:2)
+for o in "" "15=1" "15=2" "15=3" "20=2065" "20=1058" "10=1536" "17=1" "11=1" "17=1 --opt 11=1 --opt 15=1"; do
   for inp in model test; do
     echo -n "opt ${o:-default} inputs $inp : " >> $R/ab_switches.log
     timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --inputs $inp ${o:+--opt $o} 2>/dev/null | tail -1 | python -c "
