@@ -158,8 +158,8 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
                 c += t[u];
             }
         }
-        // every block gets at least one item (an empty block still has to be zero-filled)
-        const int nch = live ? max(1, (c + plan.chunk - 1) / plan.chunk) : 0;
+        // every block gets at least one item (an empty block still has to be zero-filled) unless the map is sparse
+        const int nch = live ? max(plan.min_items, (c + plan.chunk - 1) / plan.chunk) : 0;
         const int v[4] = {c, nch, nch > 1 ? nch : 0, nch > 1 ? 1 : 0};
         int inc[4];
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_seg_kernel(int *__restr
             c += t[u];
         }
     }
-    const int nch = live ? max(1, (c + plan.chunk - 1) / plan.chunk) : 0;
+    const int nch = live ? max(plan.min_items, (c + plan.chunk - 1) / plan.chunk) : 0;
     const int v[4] = {c, nch, nch > 1 ? nch : 0, nch > 1 ? 1 : 0};
     int inc[4];
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_emit_kernel(int *__rest
         const int c = offsets[(size_t)s * (plan.nblk + 1) + k];
         const int4 e = tmp[(size_t)s * plan.nblk + k];
         const int ex[4] = {base[0] + e.x, base[1] + e.y, base[2] + e.z, base[3] + e.w};
-        const int nch = max(1, (c + plan.chunk - 1) / plan.chunk);
+        const int nch = max(plan.min_items, (c + plan.chunk - 1) / plan.chunk);
         offsets[(size_t)s * (plan.nblk + 1) + k] = ex[0];
         int level = 0;
 #pragma unroll
@@ -372,7 +372,7 @@ void binned_accumulate_kernel(
     const float *__restrict__ w_lv, BinPlan plan, int S, int H, int Lq, int P,
     const int *__restrict__ offsets, const int4 *__restrict__ items,
     const int *__restrict__ n_items, const int *__restrict__ records,
-    ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
+    ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc, ZeroRole zr)
 {
     constexpr int BW = 8, PB = 32;                      // blocks: up to 8 x 4 pixels
     constexpr int R = 64 * RPL;                        // records per round, RPL per lane
@@ -422,16 +422,20 @@ void binned_accumulate_kernel(
     // Workgroup -> (slice, worker) so that all workers of a slice sit on ONE XCD (workgroup b
     // runs on XCD b % 8): a slice only reads the upstream-gradient / location / weight rows of
     // its own head, so each XCD's L2 then holds 1/8 of those tensors instead of all of them.
-    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int n_slices = plan.n_slices, workers = (int)gridDim.x - plan.zero_workers;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = bid % 8, k = bid / 8;
     const int per_xcd = (n_slices + 7) / 8;                 // slices handled by one XCD
     const int s = slice_on_xcd(xcd, k % per_xcd, per_xcd);
-    const int worker = k / per_xcd;                         // 0 .. workers-1 (grid is 8-aligned)
+    const int worker = k / per_xcd - plan.zero_workers;                  // 0 .. workers-1 (grid is 8-aligned); < 0: a sparse map's zero workers
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
     const int LP = plan.L * P;
     const int lane = threadIdx.x;
+    if (worker < 0) {
+        zero_empty_blocks<ST, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        return;
+    }
     const int mypix = lane >> 1, half = lane & 1;
     const float2 *loc2 = reinterpret_cast<const float2 *>(loc);
     const int n_it = n_items[2 * s];
@@ -722,6 +726,23 @@ inline CombinePlan combine_plan(const BinPlan &p)
     for (int k = 0; k < kMaxBinLevels; ++k) { c.start[k] = p.lv[k].start; c.W[k] = p.lv[k].W; }
     return c;
 }
+// The zero workers' geometry table of a sparse map (boxattn_scan_tail.h: ZeroRole), once per plan.
+__global__ __launch_bounds__(256) void zero_geo_kernel(BinPlan plan, int2 *__restrict__ geo)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= plan.nblk) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxBinLevels; ++l)
+        if (l < plan.L && k >= plan.lv[l].blk0) level = l;
+    BinLevel lv = plan.lv[0];
+#pragma unroll
+    for (int l = 1; l < kMaxBinLevels; ++l)
+        if (l == level) lv = plan.lv[l];
+    const BlockGeo bg = unpack_block_geo(pack_block_geo(lv, level, k));
+    geo[k] = make_int2(lv.start + bg.oy * lv.W + bg.ox, lv.W | ((bg.bh - 1) << 16) | ((bg.bw - 1) << 18));
+}
+
 template <typename ST, int C>
 __global__ __launch_bounds__(64) void combine_partials_kernel(const int4 *__restrict__ combos,
                                                               const int *__restrict__ n_items,

@@ -25,6 +25,7 @@
 #pragma once
 #include "boxattn_binplan.h"
 #include "boxattn_combine.h"
+#include "boxattn_scan_tail.h"
 
 namespace boxattn {
 
@@ -48,7 +49,8 @@ template <typename ST, int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BOXATTN_TUNE_TR_WPE : 1))) void binned_accumulate_tr_kernel(
     const ST *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
-    const int *__restrict__ records, ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
+    const int *__restrict__ records, ST *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc,
+    ZeroRole zr)
 {
     static_assert(sizeof(ST) == 2, "bf16 storage");
     static_assert(C == 16 || C == 32 || C == 64, "channels per head");
@@ -70,15 +72,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     __shared__ int last_flag;
 
     // workgroup -> (slice, worker): all workers of a slice on one XCD (see binned_accumulate_kernel)
-    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int n_slices = plan.n_slices, workers = (int)gridDim.x - plan.zero_workers;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = bid % 8, kq = bid / 8;
     const int per_xcd = (n_slices + 7) / 8;
     const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
-    const int worker = kq / per_xcd;
+    const int worker = kq / per_xcd - plan.zero_workers;        // the zero workers of a sparse map come first
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
     const int lane = threadIdx.x;
+    if (worker < 0) {
+        zero_empty_blocks<ST, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        return;
+    }
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, k-block
     const int n_it = n_items[2 * s];
 
@@ -97,7 +103,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     // operand read: 16-lane group g reads records 8 (g >> 1) + 0..3 (+ 4), channels 16 (g & 1) + 0..15
     const int g16 = lane >> 4, i16 = lane & 15;
     const unsigned tr_off = (unsigned)((8 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2);
-    const unsigned a_off = (unsigned)(col * ASB + 16 * kb);           // this lane's 8 consecutive k of pixel `col`
+    unsigned a_off = (unsigned)(col * ASB + 16 * kb);                 // this lane's 8 consecutive k of pixel `col`
+    // (opaque: knowing its low bits are zero the compiler forms a_off | 32, | 64, | 96 in three more registers --
+    // which it then spilled and reloaded every round -- instead of one address + the ds_read offset field)
+    asm volatile("" : "+v"(a_off));
 
     const int4 *my_items = items + (size_t)s * plan.item_cap;
     int4 item_n = my_items[min(worker, plan.item_cap - 1)];      // (list is heaviest first)
@@ -231,7 +240,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
         if (item.w < 0) {
             // whole rows in the storage type: lanes l and l + 32 swap half of their packed pairs
             // (v_permlane32_swap), so that each writes two 16-byte pieces (8 channels) of the pixel's row
-            const int py = col / BW, px = col % BW;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));              // (as for the partial tiles: nothing of this address is hoisted)
+            const int py = (ln & 31) / BW, px = (ln & 31) % BW;
             const bool live = py < bh && px < bw;
             ST *dst = grad_value +
                       (((size_t)b * S + lv_start + (size_t)(oy + py) * lvW + (ox + px)) * H + h) * C;
@@ -268,13 +279,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
             const bool publish = cc.tickets != nullptr;
             const __amdgpu_buffer_rsrc_t tile =
                 partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
+            // (the lane's byte offset is formed HERE, from a lane index opaque to the compiler: hoisted out of the item loop the four
+            // piece offsets sat in registers the round loop does not have -- spilled to scratch)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lane_off = (unsigned)(((ln & 31) * C + 4 * (ln >> 5)) * 4);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c = cb * 32 + 8 * g4 + 4 * kb;
-                    if (c < C)
-                        partial_store(tile, (unsigned)((col * C + c) * 4),
+                    const int c = cb * 32 + 8 * g4;
+                    if (c + 4 * kb < C)
+                        partial_store(tile, lane_off + (unsigned)(c * 4),
                                       make_float4(acc[cb][4 * g4], acc[cb][4 * g4 + 1], acc[cb][4 * g4 + 2],
                                                   acc[cb][4 * g4 + 3]), publish);
                 }
@@ -296,7 +312,8 @@ template <int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void binned_accumulate_f32_kernel(
     const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
-    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc)
+    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc,
+    ZeroRole zr)
 {
     static_assert(C == 32, "channels per head");
     constexpr int BW = 8, PB = 32, R = 64, RH = R / 2;
@@ -313,15 +330,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bi
     __shared__ __attribute__((aligned(16))) float at[RH * AP];
     __shared__ int last_flag;
 
-    const int n_slices = plan.n_slices, workers = gridDim.x;
+    const int n_slices = plan.n_slices, workers = (int)gridDim.x - plan.zero_workers;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = bid % 8, kq = bid / 8;
     const int per_xcd = (n_slices + 7) / 8;
     const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
-    const int worker = kq / per_xcd;
+    const int worker = kq / per_xcd - plan.zero_workers;        // the zero workers of a sparse map come first
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
     const int lane = threadIdx.x;
+    if (worker < 0) {
+        zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        return;
+    }
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, record of the K = 2 step
     const int n_it = n_items[2 * s];
 
@@ -427,22 +448,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bi
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         if (item.w < 0) {
-            const int py = col / BW, px = col % BW;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));              // (store addresses formed here, not hoisted and spilled)
+            const int py = (ln & 31) / BW, px = (ln & 31) % BW, kbs = ln >> 5;
             const bool live = py < bh && px < bw;
             float *dst = grad_value +
                          (((size_t)b * S + lv_start + (size_t)(oy + py) * lvW + (ox + px)) * H + h) * C;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
                 if (live)
-                    *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kb) =
+                    *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kbs) =
                         make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
         } else {
             const bool publish = cc.tickets != nullptr;
             const __amdgpu_buffer_rsrc_t tile =
                 partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lane_off = (unsigned)(((ln & 31) * C + 4 * (ln >> 5)) * 4);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
-                partial_store(tile, (unsigned)((col * C + 8 * g4 + 4 * kb) * 4),
+                partial_store(tile, lane_off + (unsigned)(32 * g4),
                               make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]), publish);
             if (publish) chunk_finish<float, C>(cc, partials, lv_start, lvW, S, H, grad_value, s, item.w, lane, &last_flag);
         }

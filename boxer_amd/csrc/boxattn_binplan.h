@@ -44,6 +44,10 @@ struct BinPlan {
     int lp_bits;          // record = (query << lp_bits) | (level*P + point)
     int n_slices;         // B * H
     int pslot_cap;        // partial-tile slots per slice (chunks of blocks cut into several items)
+    int min_items;        // work items of a block without records: 1 -- its item stores the zeros -- or 0 for sparse
+                          // maps (far more blocks than records): the empty blocks get no item, zero workers in the
+                          // accumulate launch store their zeros (boxattn_scan_tail.h: zero_empty_blocks)
+    int zero_workers;     // ... that many per slice (0 unless min_items == 0), kZeroPer blocks each
     BinLevel lv[kMaxBinLevels];
 };
 

@@ -84,7 +84,8 @@ inline hipError_t zero_async(void *p, size_t bytes, hipStream_t st)
 {
     if (!bytes) return hipSuccess;
     const int blocks = (int)std::min<size_t>((bytes / 16 + 255) / 256 + 1, 2048);
-    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)p, bytes);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)p, bytes,
+                       (int)(bytes >= ((size_t)8 << 20)));
     return hipGetLastError();
 }
 
@@ -618,6 +619,12 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     p.rec_cap = (int)rec_cap;
     p.chunk = bin_chunk(d);
     p.item_cap = (int)(blk0 + rec_cap / p.chunk + 1);
+    // sparse maps (fewer than ~2 expected records per block -- the BEV decoders: 1 000 queries against 468 x 468):
+    // grad_value is zero-filled once and the empty blocks get no work item (BinPlan::min_items)
+    // (only where the riders cannot run anyway: such a plan is always built by launch_binning, which also fills the
+    // zero workers' geometry table)
+    p.min_items = blk0 > kRideMaxBlocks && 3ll * d.Lq * d.L * d.P / 2 < 2 * blk0 ? 0 : 1;
+    p.zero_workers = p.min_items ? 0 : (int)((blk0 + kZeroPer - 1) / kZeroPer);
     // blocks with more than one chunk: sum of their chunk counts <= 2 * records / chunk
     p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / p.chunk) + 2, blk0 + rec_cap / p.chunk + 1);
     // a chunk item carries {partial slot, ordinal of its block among the chunked ones} in one word (kItemSlotBits)
@@ -638,7 +645,7 @@ std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: time stamps (b
 // hands to its backward (a few hundred KB: 1.4 MB at BoxeR-R50 shapes).  The SCRATCH -- the records
 // themselves, the fp32 partial tiles of chunked blocks -- only lives inside the backward call.
 struct PlanLayout {
-    size_t n_items, part, tickets, subtot, offsets, items, combos, scan_tmp, total;
+    size_t n_items, part, tickets, subtot, offsets, items, combos, scan_tmp, zgeo, total;
     int q_per_wg, n_wg;                                     // geometry of the bin passes
 };
 struct ScratchLayout { size_t records, partials, ctickets, total; };
@@ -671,6 +678,8 @@ inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
     // inside a segment + the segments' totals
     w.scan_tmp = o;
     if (p.nblk > kScanThreads) o += align_up(ns * ((size_t)p.nblk + kMaxBlocks / kScanThreads) * 16);
+    w.zgeo = o;                                                 // sparse maps: block geometry for the zero workers
+    if (p.zero_workers > 0) o += align_up((size_t)p.nblk * 8);
     w.total = o;
     return w;
 }
@@ -748,6 +757,9 @@ inline void launch_binning(int flavour, const float *loc, const float *w_sp, con
                        plan, d.H, d.Lq, d.P, w.q_per_wg, w.n_wg, inter, part, subtot, offsets, records, ctickets)
     if (stages & kBinCount) {
         if (pt4) BOXATTN_BIN(false, false, 4); else BOXATTN_BIN(false, false, 1);
+        if (plan.zero_workers > 0)         // sparse map: the zero workers' geometry table is part of the plan
+            hipLaunchKernelGGL(zero_geo_kernel, dim3((plan.nblk + 255) / 256), dim3(256), 0, st, plan,
+                               (int2 *)(pbuf + w.zgeo));
     }
 #ifndef BOXATTN_TUNE_SCAN_FUSE_WG
 #define BOXATTN_TUNE_SCAN_FUSE_WG 48   // up to this many bin workgroups per slice the block scan does kernel A's work too
@@ -950,7 +962,7 @@ template <typename ST, int G, bool INST>
 int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, const float *loc, const float *w_sp,
                       const float *w_lv, const Dims &d, const BinPlan &plan, const int *offsets, const int4 *items,
                       const int *n_items, const int *records, ST *grad_value, float *partials,
-                      const ChunkCombine &cc, hipStream_t st)
+                      const ChunkCombine &cc, const ZeroRole &zr, hipStream_t st)
 {
     constexpr int C = 4 * G;
     const int ns = d.B * d.H, ns8 = (ns + 7) / 8 * 8;
@@ -959,21 +971,21 @@ int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, cons
     if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
         if (acc == kAccTr) {
             launch_accumulate_tr(C, grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(ST), plan, d.S, d.H, d.Lq, items,
-                                 n_items, records, grad_value, partials, wg_per_slice, ns8, cc, st);
+                                 n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st);
             return finish();
         }
     }
     if constexpr (std::is_same<ST, float>::value && !INST && C == 32) {
         if (acc == kAccF32) {
             launch_accumulate_f32(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
-                                  n_items, records, grad_value, partials, wg_per_slice, ns8, cc, st);
+                                  n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st);
             return finish();
         }
     }
     if (acc != kAccValu) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((binned_accumulate_kernel<ST, C, INST, 1, false>), dim3(wg_per_slice, ns8), dim3(64), 0, st,
+    hipLaunchKernelGGL((binned_accumulate_kernel<ST, C, INST, 1, false>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st,
                        grad_out, grad_mask, loc, w_sp, w_lv, plan, d.S, d.H, d.Lq, d.P, offsets, items, n_items,
-                       records, grad_value, partials, cc);
+                       records, grad_value, partials, cc, zr);
     return finish();
 }
 
@@ -1015,8 +1027,10 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                        own_combine ? nullptr : (int *)(sbuf + sl.ctickets));
     ChunkCombine cc{};
     if (!own_combine) cc = ChunkCombine{(int *)(sbuf + sl.ctickets), combos, plan.nblk, plan.pslot_cap};
+    // (sparse maps: zero workers in front of the accumulate grid store the zeros of the blocks without records)
+    const ZeroRole zr{offsets, (const int2 *)(pbuf + pl.zgeo)};
     int rc = launch_accumulate<ST, G, INST>(acc, grad_out, grad_mask, loc, w_sp, w_lv, d, plan, offsets, items,
-                                            n_items, records, grad_value, partials, cc, st);
+                                            n_items, records, grad_value, partials, cc, zr, st);
     if (rc) return rc;
     if (own_combine) {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);

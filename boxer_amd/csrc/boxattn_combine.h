@@ -149,6 +149,7 @@ __device__ __forceinline__ void chunk_finish(const ChunkCombine cc, const float 
                                              int s, int item_w, int lane, int *lds_flag)
 {
     stores_left();
+    asm volatile("" : "+v"(lane));       // (the caller's loops get no hoisted per-lane addresses of this rarely taken tail)
     const int ordinal = item_w >> kItemSlotBits;
     const int4 cb = cc.combos[(size_t)s * cc.nblk + ordinal];
     if (!last_arriver<64>(cc.tickets + (size_t)s * cc.nblk + ordinal, cb.z, lds_flag)) return;

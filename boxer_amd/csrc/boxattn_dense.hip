@@ -53,12 +53,12 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,
                           int H, int Lq, const int4 *items, const int *n_items, const int *records,
                           uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc,
-                          hipStream_t st)
+                          const ZeroRole &zr, hipStream_t st)
 {
 #define BOXATTN_ACC_TR(C_)                                                                              \
-    hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_>), dim3(wg_per_slice, ns8), dim3(64), 0, st, \
+    hipLaunchKernelGGL((binned_accumulate_tr_kernel<uint16_t, C_>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st, \
                        grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records,     \
-                       grad_value, partials, cc)
+                       grad_value, partials, cc, zr)
     switch (C) {
     case 16: BOXATTN_ACC_TR(16); break;
     case 32: BOXATTN_ACC_TR(32); break;
@@ -69,10 +69,11 @@ void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes
 
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                            const int4 *items, const int *n_items, const int *records, float *grad_value,
-                           float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, hipStream_t st)
+                           float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,
+                           hipStream_t st)
 {
-    hipLaunchKernelGGL((binned_accumulate_f32_kernel<32>), dim3(wg_per_slice, ns8), dim3(64), 0, st, grad_out,
-                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc);
+    hipLaunchKernelGGL((binned_accumulate_f32_kernel<32>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st, grad_out,
+                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc, zr);
 }
 
 }  // namespace boxattn

@@ -174,14 +174,20 @@ __global__ __launch_bounds__(256) void bwd_generic_kernel(
 // a memset node at the head of a captured HIP graph left the kernel nodes behind it reading stale
 // copies of tensors written outside the graph between replays (ROCm 7.2, MI355X: found with the
 // training forward's ticket clear, tests/test_gpu_parity.py::test_forward_backward_under_graph_capture).
-__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned char *__restrict__ p, size_t bytes)
+__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned char *__restrict__ p, size_t bytes, int streaming)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;       // bytes up to 16-byte alignment
     const size_t h = head < bytes ? head : bytes, n16 = (bytes - h) / 16;
     for (size_t i = i0; i < h; i += stride) p[i] = 0;
     uint4 *q = reinterpret_cast<uint4 *>(p + h);
-    for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (streaming) {                       // big fills (a sparse map's grad_value): non-temporal, nobody reads the zeros soon
+        typedef unsigned int zf_u32x4 __attribute__((ext_vector_type(4)));
+        for (size_t i = i0; i < n16; i += stride)
+            __builtin_nontemporal_store(zf_u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<zf_u32x4 *>(q + i));
+    } else {
+        for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     for (size_t i = h + n16 * 16 + i0; i < bytes; i += stride) p[i] = 0;
 }
 

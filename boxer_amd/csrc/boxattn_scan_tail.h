@@ -121,8 +121,8 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
                 c[j] += tv[uu];
             }
         }
-        // every block gets at least one item (an empty block still has to be zero-filled)
-        nch[j] = k < plan.nblk ? max(1, (c[j] + plan.chunk - 1) / plan.chunk) : 0;
+        // every block gets at least one item (an empty block still has to be zero-filled) unless the map is sparse
+        nch[j] = k < plan.nblk ? max(plan.min_items, (c[j] + plan.chunk - 1) / plan.chunk) : 0;
         sum[0] += c[j]; sum[1] += nch[j]; sum[2] += nch[j] > 1 ? nch[j] : 0; sum[3] += nch[j] > 1 ? 1 : 0;
     }
     int run[4], tot[4];
@@ -173,6 +173,55 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
         o.offsets[(size_t)s * (plan.nblk + 1) + plan.nblk] = tot[0];
         o.n_items[2 * s] = tot[1];
         o.n_items[2 * s + 1] = tot[3];             // chunked blocks
+    }
+}
+
+// Sparse maps (BinPlan::min_items == 0: far more blocks than records -- 1 000 queries against a 468 x 468 BEV
+// map): the blocks without records get no work item; their rows of grad_value are zeroed by ZERO WORKERS, extra
+// single-wave workgroups in front of the accumulate launch's grid.  A zero worker takes `per` consecutive blocks
+// of its slice, finds the empty ones in the block offsets (one coalesced load per 64 blocks) and streams their
+// zeros -- no per-block latency chain (as one-wave items the empty blocks ran at 2.9 TB/s: an item is a load
+// -> store round trip however little it stores).  Disjoint from the rows the items write: no ordering needed.
+constexpr int kZeroPer = 32;     // blocks per zero worker (BinPlan::zero_workers of them per slice)
+struct ZeroRole {
+    const int *offsets;          // [slice][nblk + 1], written by the scan
+    const int2 *geo;             // [nblk] {first pixel of the block (index into S), W | bh - 1 << 16 | bw - 1 << 18}: zero_geo_kernel (boxattn_binned.h)
+};
+// (The block geometry comes from a table, not from the plan in the kernel arguments: selecting a level's
+// entry there costs the accumulate kernels ~40 scalar registers at their top, which they do not have --
+// scalar spills into vector lanes, vector spills to scratch.)
+template <typename ST, int C>
+__device__ __forceinline__ void zero_empty_blocks(const ZeroRole zr, int nblk, int s, int zw, int S, int H,
+                                                  ST *__restrict__ grad_value, int lane)
+{
+    constexpr int PPR = C * (int)sizeof(ST) / 16;            // 16-byte pieces of a (pixel, head) row
+    constexpr int PIX = 64 / PPR;                            // pixels a wave covers per store
+    typedef unsigned int zr_u32x4 __attribute__((ext_vector_type(4)));
+    const int b = s / H, h = s % H;
+    const int *off = zr.offsets + (size_t)s * (nblk + 1);
+    const int k_lo = zw * kZeroPer, k_hi = min(nblk, k_lo + kZeroPer);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+        const int k = min(k0 + lane, k_hi - 1);
+        const bool empty = k0 + lane < k_hi && off[k + 1] == off[k];
+        const int2 g = zr.geo[k];
+        unsigned long long m = __builtin_amdgcn_ballot_w64(empty);
+        while (m) {
+            const int j = (int)__builtin_ctzll(m);            // wave-uniform
+            m &= m - 1;
+            const int pix0 = __builtin_amdgcn_readlane(g.x, j), gy = __builtin_amdgcn_readlane(g.y, j);
+            const int W = gy & 0xffff, bh = ((gy >> 16) & 3) + 1, bw = ((gy >> 18) & 7) + 1;
+#pragma unroll
+            for (int p0 = 0; p0 < 32; p0 += PIX) {
+                const int pix = p0 + lane / PPR, py = pix >> 3, px = pix & 7;
+                if (pix < 32 && py < bh && px < bw) {
+                    ST *row = grad_value + (((size_t)b * S + pix0 + py * W + px) * H + h) * C;
+                    // (plain stores: the two 64-byte halves of a bf16 line belong to neighbouring heads = slices on
+                    // the same XCD, whose L2 merges them -- non-temporal they leave as half lines, C5 bf16 accumulate
+                    // 56 -> 67 us; float32 rows, whole lines, measured the same either way)
+                    reinterpret_cast<zr_u32x4 *>(row)[lane % PPR] = zr_u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
     }
 }
 

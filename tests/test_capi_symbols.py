@@ -90,6 +90,23 @@ def test_no_packed_float32_next_to_mfma(lib):
     assert not offenders, offenders
 
 
+def test_no_kernel_spills_to_scratch(lib):
+    """Code-object guard: a spilled value is a scratch store / load
+    pair with a full memory wait -- in the round-4 point-gradient kernel four spilled loads were four serial HBM
+    round trips (51 -> 65 us).  No kernel of the shipped library may use scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    from boxer_amd import _lib
+    rows = kernel_resources.kernels(_lib.LIB_PATH)
+    assert len(rows) > 50, len(rows)
+    spilling = [(name, scratch) for name, _v, _s, _lds, scratch in rows if int(scratch) != 0]
+    assert not spilling, spilling
+
+
 def test_build_flags_are_part_of_the_staleness_check(tmp_path, monkeypatch):
     """A change of compiler flags must rebuild like a change of sources (the object cache used to be keyed on
     source mtimes only)."""

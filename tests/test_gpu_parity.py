@@ -311,15 +311,21 @@ def test_binned_backward_records_per_item(dtype, chunk):
                          ids=["1024", "1056", "2048", "2lv"])
 def test_block_scan_over_several_workgroups(levels):
     """More than 1 024 blocks per (image, head) slice: the block scan runs as bin_scan_seg_kernel +
-    bin_scan_emit_kernel; few queries, so most blocks are empty and have to come back as zeros."""
-    g = _seeded(levels, 1, 2, 32, 150, 4, seed=32)
-    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
-                                g["grad_out"])
-    for dtype in (torch.float32, torch.bfloat16):
-        out, gv, gl, ga = run_box(g, dtype, "binned")
-        close(gv, want[0], dtype, "grad_value")
-        close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
-        close(ga, want[2], torch.float32, "grad_attn")
+    bin_scan_emit_kernel.  150 queries: a SPARSE map (BinPlan::min_items == 0) -- the blocks without records get
+    no work item, zero workers in the accumulate launch store their zeros (into poisoned memory here);
+    3 000 queries: every block has its item."""
+    for n_queries in (150, 3000):
+        g = _seeded(levels, 1, 2, 32, n_queries, 4, seed=32)
+        want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
+                                    g["grad_out"])
+        for dtype in (torch.float32, torch.bfloat16):
+            junk = [torch.full(g["value"].shape, float("nan"), device="cuda", dtype=dtype) for _ in range(3)]
+            del junk                                   # poison what the allocator hands out next
+            out, gv, gl, ga = run_box(g, dtype, "binned")
+            assert torch.isfinite(gv.float()).all()
+            close(gv, want[0], dtype, "grad_value")
+            close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
+            close(ga, want[2], torch.float32, "grad_attn")
 
 
 def test_binned_backward_clustered_points():
