@@ -1,0 +1,269 @@
+// Host-side planning of a call: shapes -> BinPlan / DensePlan, buffer layouts (plan, scratch, state), which
+// accumulate kernel and record format a call uses.  Pure functions of the dimensions, the level tables and the
+// option switches -- no launches.  Included by boxattn_capi.hip only, inside its unnamed namespace, behind the
+// option switches (opt(), kOpt*), Dims and fast_group() it uses.
+#pragma once
+
+// ------------------------------------------------------- binned backward (boxattn_binned.h)
+constexpr int kChunk = 1024, kChunkBig = 1536;   // records per work item (upper bound of the rule below; what it uses beyond)
+// Records per work item.  One wavefront works an item off 64 records a round, and a round is a
+// chain of dependent latencies (~3-5 us), so the kernel lasts at least rounds-per-item rounds:
+// with few sample points (the decoders: 300 queries) 1 024-record items leave a handful of waves
+// running 16 rounds while the rest of the chip idles.  Aim at ~256 items per (image, head) slice
+// -- about the wave slots a slice gets -- between 128 and kChunk records.
+inline int bin_chunk(const Dims &d)
+{
+    const int forced = opt(kOptBinChunk);
+    if (forced > 0) return std::min(4096, std::max(64, (forced + 63) / 64 * 64));
+    const long long rec_est = 3ll * d.Lq * d.L * d.P / 2;          // ~1.4 records per point
+    const long long c = (rec_est / 256 + 63) / 64 * 64;
+    // (encoder-sized problems: 1 536 -- fewer partial tiles for the combine step, measured at C2 / C2' against
+    // 1 024 / 1 280 / 2 048: profiles/r04_chunk_sweep.log)
+    return c >= kChunk ? kChunkBig : (int)std::max<long long>(128, c);
+}
+
+// Which accumulate kernel a call runs, and with it the record format of the bin passes:
+//   kAccTr   bf16 box attention, C = 16 / 32 / 64: binned_accumulate_tr_kernel (v_mfma_f32_32x32x16_bf16) from
+//            16-byte records {id, x, y, weight}, contiguous query ranges per bin workgroup;
+//   kAccF32  float32 box attention, C = 32, opt-in (boxattn_set_option(19, 2)): binned_accumulate_f32_kernel
+//            (v_mfma_f32_32x32x2_f32: float32-exact), 16-byte records -- measured at C2 97 us against the VALU
+//            kernel's 102 on model-like inputs (the matrix pipe is busy 63 us of them), 100 against 133 on
+//            uniformly random ones;
+//   kAccValu everything else (float32, instance attention): binned_accumulate_kernel, 4-byte records, queries
+//            interleaved over the bin workgroups.
+enum AccKind { kAccValu = 0, kAccTr = 1, kAccF32 = 2 };
+inline bool accumulate_tr_ok(const Dims &d)          // 32-bit row offsets: grad_out below 2 GB
+{
+    return (d.C == 16 || d.C == 32 || d.C == 64) && (size_t)d.B * d.Lq * d.H * d.C * 2 < kAccTrMaxBytes &&
+           d.Lq < (1 << 24) && d.H * d.C * 2 < (1 << 24);
+}
+inline bool f32_mfma_ok(const Dims &d)
+{
+    return opt(kOptAccF32) == 2 && d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes &&
+           d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
+}
+template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
+{
+    if constexpr (!INST && std::is_same<ST, bf16_t>::value) {
+        if (accumulate_tr_ok(d)) return kAccTr;
+    }
+    if constexpr (!INST && std::is_same<ST, float>::value) {
+        if (f32_mfma_ok(d)) return kAccF32;
+    }
+    return kAccValu;
+}
+// the workspace query only knows the storage type and the dimensions: room for 16-byte records
+// whenever a flavour of that type may write them
+inline bool wide_workspace(bool is_bf16, const Dims &d)
+{
+    return is_bf16 ? accumulate_tr_ok(d) : f32_mfma_ok(d);
+}
+constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
+{
+    constexpr int BW = 8, BH = 4;
+    p.L = d.L;
+    long long blk0 = 0, next_start = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1], st = ls[l];
+        // standard packed layout only: level l starts where level l-1 ends (every grad_value
+        // row then has exactly one owner block)
+        if (hl < 0 || wl < 0 || hl > INT32_MAX || wl > INT32_MAX || st != next_start ||
+            st + hl * wl > d.S)
+            return false;
+        next_start = st + hl * wl;
+        p.lv[l].H = (int)hl;
+        p.lv[l].W = (int)wl;
+        p.lv[l].start = (int)st;
+        p.lv[l].nbx = (int)((wl + BW - 1) / BW);
+        p.lv[l].nby = (int)((hl + BH - 1) / BH);
+        // blk_of(): floor(x nb / size) by multiply-high is exact while x nb < 2^32 / size
+        if ((unsigned long long)wl * wl * p.lv[l].nbx >= (1ull << 32) ||
+            (unsigned long long)hl * hl * p.lv[l].nby >= (1ull << 32))
+            return false;
+        p.lv[l].mw = wl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)wl + 1) : 0u;
+        p.lv[l].mh = hl > 1 ? (unsigned)((1ull << 32) / (unsigned long long)hl + 1) : 0u;
+        // pack_block_geo(): n / nbx and n / nby by multiply-high for every n it can ask for, checked (once per
+        // (range, divisor) pair of the process: make_plan runs on every call)
+        const auto nb_magic = [](long long nmax, int nb) -> unsigned {
+            if (nb <= 1 || nmax >= (1ll << 24)) return 0u;
+            static std::mutex mu;
+            static std::map<std::pair<long long, int>, unsigned> known;
+            std::lock_guard<std::mutex> g(mu);
+            const auto it = known.find({nmax, nb});
+            if (it != known.end()) return it->second;
+            unsigned m = (unsigned)((1ull << 32) / (unsigned long long)nb + 1);
+            for (long long n = 0; n <= nmax && m; ++n)
+                if ((unsigned)(((unsigned long long)n * m) >> 32) != (unsigned)(n / nb)) m = 0u;
+            known[{nmax, nb}] = m;
+            return m;
+        };
+        p.lv[l].mnx = nb_magic(std::max<long long>((long long)p.lv[l].nbx * p.lv[l].nby, (long long)p.lv[l].nbx * wl + p.lv[l].nbx), p.lv[l].nbx);
+        p.lv[l].mny = nb_magic((long long)p.lv[l].nby * hl + p.lv[l].nby, p.lv[l].nby);
+        p.lv[l].blk0 = (int)blk0;
+        blk0 += (long long)p.lv[l].nbx * p.lv[l].nby;
+    }
+    // ... and the levels cover all of S: the binned kernels only store the rows a level block
+    // owns, a padded tail (S > sum H_l W_l) would stay uninitialised (the atomic path zero-fills)
+    if (next_start != d.S) return false;
+    const long long rec_cap = 4ll * d.Lq * d.L * d.P;
+    if (blk0 == 0 || blk0 > kMaxBlocks || rec_cap > INT32_MAX / 2 ||
+        (long long)d.B * d.Lq * d.H > INT32_MAX || (long long)d.B * d.Lq * d.P * d.H > INT32_MAX)
+        return false;
+    int lp_bits = 0;
+    while ((1ll << lp_bits) < (long long)d.L * d.P) ++lp_bits;
+    if (((long long)d.Lq << lp_bits) > INT32_MAX) return false;
+    if ((long long)d.L * d.P > (1 << 16)) return false;       // keeps per-workgroup point counts < 2^24
+    p.lp_bits = lp_bits;
+    p.n_slices = d.B * d.H;
+    p.nblk = (int)blk0;
+    p.rec_cap = (int)rec_cap;
+    p.chunk = bin_chunk(d);
+    p.item_cap = (int)(blk0 + rec_cap / p.chunk + 1);
+    // sparse maps (fewer than ~2 expected records per block -- the BEV decoders: 1 000 queries against 468 x 468):
+    // grad_value is zero-filled once and the empty blocks get no work item (BinPlan::min_items)
+    // (only where the riders cannot run anyway: such a plan is always built by launch_binning, which also fills the
+    // zero workers' geometry table)
+    p.min_items = blk0 > kRideMaxBlocks && 3ll * d.Lq * d.L * d.P / 2 < 2 * blk0 ? 0 : 1;
+    p.zero_workers = p.min_items ? 0 : (int)((blk0 + kZeroPer - 1) / kZeroPer);
+    // blocks with more than one chunk: sum of their chunk counts <= 2 * records / chunk
+    p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / p.chunk) + 2, blk0 + rec_cap / p.chunk + 1);
+    // a chunk item carries {partial slot, ordinal of its block among the chunked ones} in one word (kItemSlotBits)
+    if (p.pslot_cap >= (1 << kItemSlotBits) || blk0 >= (1 << (31 - kItemSlotBits))) return false;
+    return true;
+}
+
+inline bool make_plan(const Dims &d, const int64_t *sh, const int64_t *ls, BinPlan &p)
+{
+    if (!sh || !ls || !d.valid() || fast_group(d) == 0 || d.L > kMaxBinLevels) return false;
+    return make_plan_blocks(d, sh, ls, p);
+}
+
+std::atomic<float *> g_dense_dbg{nullptr};      // debugging aid: time stamps (boxattn_set_debug_buffer)
+
+// The PLAN of a backward -- everything the binning knows before the records are written: per bin workgroup
+// and block the first slot, per block the first record, the work-item list -- is what a training forward
+// hands to its backward (a few hundred KB: 1.4 MB at BoxeR-R50 shapes).  The SCRATCH -- the records
+// themselves, the fp32 partial tiles of chunked blocks -- only lives inside the backward call.
+struct PlanLayout {
+    size_t n_items, part, tickets, subtot, offsets, items, combos, scan_tmp, zgeo, total;
+    int q_per_wg, n_wg;                                     // geometry of the bin passes
+};
+struct ScratchLayout { size_t records, partials, ctickets, total; };
+
+inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
+{
+    const size_t ns = (size_t)d.B * d.H;
+    PlanLayout w;
+    // ~2048 workgroups of 256 threads' worth of bin workgroups
+    // ... and at most kScanSub * kScanWgPerSub per slice (the scan's two levels)
+    const long long wg_target = bin_wg_target();
+    w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
+    w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
+                                          (kScanSub * kScanWgPerSub));
+    // ... and every workgroup initialises, flushes and has scanned one counter per block: give it
+    // at least 4 points per block (few queries on a big map: 1 000 queries on 468 x 468 = 6 903
+    // blocks per slice now use 1 workgroup per slice instead of 67)
+    const long long lp = (long long)d.L * d.P;
+    w.q_per_wg = (int)std::max<long long>(w.q_per_wg, (4ll * p.nblk + lp - 1) / lp);
+    w.n_wg = (d.Lq + w.q_per_wg - 1) / w.q_per_wg;
+    size_t o = 0;
+    w.n_items = o; o += align_up(ns * 2 * 4);
+    w.tickets = o; o += align_up(ns * kRideTickets * 4);        // the riders' hand-offs (boxattn_scan_tail.h)
+    w.part = o;    o += align_up(ns * (size_t)w.n_wg * (size_t)p.nblk * 4);
+    w.subtot = o;  o += align_up(ns * kScanSub * (size_t)p.nblk * 4);
+    w.offsets = o; o += align_up(ns * (p.nblk + 1) * 4);
+    w.items = o;   o += align_up(ns * p.item_cap * 16);
+    w.combos = o;  o += align_up(ns * (size_t)p.nblk * 16);
+    // multi-workgroup block scan (more than kScanThreads blocks per slice): per-block prefixes
+    // inside a segment + the segments' totals
+    w.scan_tmp = o;
+    if (p.nblk > kScanThreads) o += align_up(ns * ((size_t)p.nblk + kMaxBlocks / kScanThreads) * 16);
+    w.zgeo = o;                                                 // sparse maps: block geometry for the zero workers
+    if (p.zero_workers > 0) o += align_up((size_t)p.nblk * 8);
+    w.total = o;
+    return w;
+}
+// `wide`: 16-byte records {id, x, y, weight} instead of 4-byte point ids
+inline ScratchLayout scratch_layout(const Dims &d, const BinPlan &p, bool wide)
+{
+    const size_t ns = (size_t)d.B * d.H;
+    ScratchLayout w;
+    size_t o = 0;
+    w.ctickets = o; o += align_up(ns * (size_t)p.nblk * 4);      // in-launch combine (chunk_finish)
+    w.records = o;  o += align_up(ns * (size_t)p.rec_cap * (wide ? 16 : 4));
+    w.partials = o; o += align_up(ns * (size_t)p.pslot_cap * 32 * d.C * 4);
+    w.total = o;
+    return w;
+}
+
+// The caller's state buffer (include/boxattn.h): [kDenseStatSlots pairs of uint64 locality counters = 1 KiB]
+// [tickets: B * H * kRideTickets ints].  The counters come FIRST, at a fixed place: one buffer serves calls of
+// every shape on its stream, and what one shape's calls add to must never be another shape's tickets.
+constexpr size_t kStatBytes = (size_t)kDenseStatSlots * 2 * sizeof(unsigned long long);
+
+// May the count / fill passes and the scans of this plan run as riders (boxattn_ride.h)?
+inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
+{
+    return opt(kOptRiders) != 1 && plan.nblk <= kRideMaxBlocks && w.n_wg <= kScanSub * kScanWgPerSub;
+}
+
+// ------------------------------------------------- window-staged encoder kernels (boxattn_dense.h)
+// Encoder case: one query per pixel of packed levels, bf16 storage, C = 32, 2x2 points, <= 4 levels.
+inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p)
+{
+    if (!sh || !ls || !d.valid() || opt(kOptDense) == 1 || g_variant == 1 || g_variant == 2) return false;
+    if (d.Lq != d.S || d.C != 32 || d.P != 4 || d.L > kDenseMaxLevels || d.B < 1 || d.S < 1) return false;
+    if ((size_t)d.B * d.Lq * d.H * d.L * d.P >= (1ull << 31)) return false;       // 32-bit point ids
+    if (d.n_value() * sizeof(bf16_t) >= kOobOffset) return false;
+    p = DensePlan{};
+    p.dbg = g_dense_dbg.load();
+    p.L = d.L; p.B = d.B; p.Lq = d.Lq; p.S = d.S; p.H = d.H;
+    const auto magic = [](int dd) { return dd == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)dd); };
+    p.mag_h = magic(d.H);
+    long long next = 0;
+    for (int l = 0; l < d.L; ++l) {
+        const long long hl = sh[2 * l], wl = sh[2 * l + 1];
+        if (hl <= 0 || wl <= 0 || hl > 32000 || wl > 32000 || ls[l] != next) return false;
+        next += hl * wl;
+        DenseLevel &v = p.lv[l];
+        v.H = (int)hl; v.W = (int)wl; v.start = (int)ls[l];
+        v.ntx = (int)((wl + kDenseTile - 1) / kDenseTile);
+        v.ntiles = v.ntx * (int)((hl + kDenseTile - 1) / kDenseTile);
+        if ((long long)v.ntiles * d.B * d.H >= (1 << 24)) return false;      // x * n and the block index < 2^31
+        v.n_all = (unsigned)(v.ntiles * d.B);
+        v.mag_ntx = magic(v.ntx);
+        v.mag_ntiles = magic(v.ntiles);
+    }
+    if (next != d.S) return false;
+    // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
+    // (r = W_l / W_lq); their points lie a quarter box (ref / 4 pixels of the query's level, i.e.
+    // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further.
+    // The levels are staged coarsest first into the workgroup's kDenseLdsBytes of LDS; what does
+    // not fit (a coarse tile's window on a fine level) is not staged.
+    const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
+    const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
+    for (int lq = 0; lq < d.L; ++lq) {
+        int used = 0;
+        for (int l = d.L - 1; l >= 0; --l) {
+            DenseWin &w = p.win[lq][l];
+            const float rx = (float)p.lv[l].W / (float)p.lv[lq].W, ry = (float)p.lv[l].H / (float)p.lv[lq].H;
+            const float mx = rx * ref4 * (1.0f + jit), my = ry * ref4 * (1.0f + jit);
+            const int cols = (int)std::ceil(rx * (kDenseTile - 1) + 2 * mx) + 2;
+            const int rows = (int)std::ceil(ry * (kDenseTile - 1) + 2 * my) + 2;
+            // 16.16 fixed point (a placement heuristic: any rounding will do, tile columns < 2^12)
+            w.ax = (int)std::lround(kDenseTile * rx * 65536.0f); w.bx = (int)std::floor((0.5f * rx - 0.5f - mx) * 65536.0f);
+            w.ay = (int)std::lround(kDenseTile * ry * 65536.0f); w.by = (int)std::floor((0.5f * ry - 0.5f - my) * 65536.0f);
+            if (rx > 8.0f || ry > 8.0f) { w.ax = w.ay = 0; }      // (not staged anyway; keeps tx * ax inside 31 bits)
+            const int need = rows * dense_win_pitch16(cols);       // in 16-byte units
+            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && 16 * (used + need) <= kDenseZeroOff;
+            w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, used);
+            if (fits) used += need;
+        }
+    }
+    return true;
+}
+
