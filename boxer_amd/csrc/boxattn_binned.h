@@ -198,9 +198,10 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_kernel(int *__restrict_
             for (int l = 1; l < kMaxBinLevels; ++l)
                 if (l == level) lv = plan.lv[l];
             const int geo = (int)pack_block_geo(lv, level, k);
+            const int csz = chunk_records(c, nch);
             for (int j = 0; j < nch; ++j)
                 items[(size_t)s * plan.item_cap + (tot_items - 1 - (ex[1] + j))] =   // record range inside the slice
-                    make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
+                    make_int4(geo, ex[0] + j * csz, ex[0] + min(c, (j + 1) * csz),
                               nch > 1 ? (ex[2] + j) | (ex[3] << kItemSlotBits) : -1);   // .w: see kItemSlotBits
             if (nch > 1)
                 combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
@@ -337,9 +338,10 @@ __global__ __launch_bounds__(kScanThreads) void bin_scan_emit_kernel(int *__rest
         for (int l = 1; l < kMaxBinLevels; ++l)
             if (l == level) lv = plan.lv[l];
         const int geo = (int)pack_block_geo(lv, level, k);
+        const int csz = chunk_records(c, nch);
         for (int j = 0; j < nch; ++j)
             items[(size_t)s * plan.item_cap + (all[1] - 1 - (ex[1] + j))] =      // heaviest first
-                make_int4(geo, ex[0] + j * plan.chunk, ex[0] + min(c, (j + 1) * plan.chunk),
+                make_int4(geo, ex[0] + j * csz, ex[0] + min(c, (j + 1) * csz),
                           nch > 1 ? (ex[2] + j) | (ex[3] << kItemSlotBits) : -1);
         if (nch > 1) combos[(size_t)s * plan.nblk + ex[3]] = make_int4(geo, ex[2], nch, 0);
     }

@@ -756,12 +756,12 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                                       grad_sp, grad_lv, st, gs, nullptr, nullptr, dp);
     }
     // Chunked blocks: summed by their last chunk inside the accumulate launch (chunk_finish; the fill pass -- riding
-    // or not -- clears the blocks' tickets) where the step is a chain of short launches, i.e. few sample points;
-    // by combine_partials_kernel behind it for the encoder-sized problems -- every chunk item pays a write-through
-    // + ticket round trip (~6 us of its wave slot) for the hand-off, which at 2 600 chunk items is as much as the
-    // extra launch, and more at COCO-rect shapes (C2' bf16: accumulate 96 us against 82 + 9).
-    const bool small = (long long)d.Lq * d.L * d.P < 65536;
-    const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2 || (opt(kOptRiders) == 0 && !small);
+    // or not -- clears the blocks' tickets) wherever the riders run: one launch less, C2 bf16 125.7 -> 122.9 us, C2 fp32
+    // 245 -> 240, C2' fp32 420 -> 411 (profiles/r04_combine_sweep.log; with 1 024-record chunks and a spilling store
+    // path it had been the other way round at encoder sizes).  Maps too big for the riders (the BEV encoder) keep
+    // combine_partials_kernel behind the accumulate launch (C5' bf16 464 against 478 us).
+    const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2 ||
+                             (opt(kOptRiders) == 0 && !riders_ok(plan, pl));
     if (!filled)
         launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill,
                        own_combine ? nullptr : (int *)(sbuf + sl.ctickets));

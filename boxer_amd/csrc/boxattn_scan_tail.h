@@ -37,6 +37,10 @@ __device__ __forceinline__ unsigned pack_block_geo(const BinLevel &lv, int level
     return (unsigned)oy | ((unsigned)ox << 12) | ((unsigned)(bh - 1) << 24) |
            ((unsigned)(bw - 1) << 26) | ((unsigned)level << 29);
 }
+// Records per item of a block with c records cut into nch chunks: EQUAL shares (a block of 9 300 records in chunks of
+// 1 536 is seven items of 1 329, not six of 1 536 and one of 84: the longest item sets the tail of the accumulate
+// launch, and a partial tile + ticket costs the same whatever it sums).  (nch - 1) * share < c for every nch <= c.
+__device__ __forceinline__ int chunk_records(int c, int nch) { return nch > 1 ? (c + nch - 1) / nch : c; }
 constexpr int kScanSub = 8, kScanWgPerSub = 16;   // sub-ranges of bin workgroups per slice, workgroups per sub-range at most
 constexpr int kScanThreads = 1024;     // bin_scan_kernel: one workgroup per slice walks the blocks 1024 at a time
 constexpr int kRideTickets = kScanSub + 1;        // per slice: one ticket per sub-range + the slice's
@@ -161,9 +165,10 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
                 if (k >= lv_lds[l].blk0) level = l;
             const BinLevel lv = lv_lds[level];
             const int geo = (int)pack_block_geo(lv, level, k);
+            const int csz = chunk_records(c[j], nch[j]);
             for (int jj = 0; jj < nch[j]; ++jj)           // heaviest first, as bin_scan_kernel lists them
                 o.items[(size_t)s * plan.item_cap + (tot[1] - 1 - (run[1] + jj))] =
-                    make_int4(geo, run[0] + jj * plan.chunk, run[0] + min(c[j], (jj + 1) * plan.chunk),
+                    make_int4(geo, run[0] + jj * csz, run[0] + min(c[j], (jj + 1) * csz),
                               nch[j] > 1 ? (run[2] + jj) | (run[3] << kItemSlotBits) : -1);
             if (nch[j] > 1) o.combos[(size_t)s * plan.nblk + run[3]] = make_int4(geo, run[2], nch[j], 0);
             run[0] += c[j]; run[1] += nch[j]; run[2] += nch[j] > 1 ? nch[j] : 0; run[3] += nch[j] > 1 ? 1 : 0;

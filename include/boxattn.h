@@ -344,9 +344,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      (0 = default 4, BoxeR's reference windows).  Placement only: results do not depend on them.
  *  15  riders: the count pass + scans inside the training forward's launch, the fill pass
  *      inside the point-gradient launch, chunked blocks summed inside the accumulate launch:
- *      0 default (on; chunked blocks are summed inside the accumulate launch for problems of < 65 536 sample points
- *      per (image, head), by a combine launch behind it otherwise), 1 off (launches of their own), 2 on with the
- *      combine always a launch of its own, 3 on with the combine always inside
+ *      0 default (on; chunked blocks are summed inside the accumulate launch wherever the riders run -- maps of up
+ *      to 1 024 blocks per (image, head) -- and by a combine launch behind it otherwise), 1 off (launches of their
+ *      own), 2 on with the combine always a launch of its own, 3 on with the combine always inside
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands

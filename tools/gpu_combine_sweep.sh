@@ -1,6 +1,3 @@
-#!/bin/bash
-# Records per work item of the accumulate kernels (boxattn_set_option(10)) at the encoder-sized workloads.
-#   gpurun --timeout 1200 -- bash tools/gpu_chunk_sweep.sh      -> gpurun_out/chunk_sweep.log
 export TMPDIR=/tmp
 run() {
   timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
@@ -11,6 +8,6 @@ try:
 except Exception as e: print('bench failed', sys.argv[1:], e)
 " "$@"
 }
-for wl in C2 C2p; do for dt in bf16 fp32; do for c in ${CHUNKS:-1024 1536 2048 3072}; do
-  run --workload $wl --dtype $dt --opt 10=$c
-done; done; done 2>&1 | tee gpurun_out/chunk_sweep.log
+for wl in C2 C2p C5p C3p; do for dt in bf16 fp32; do for o in 0 3; do
+  run --workload $wl --dtype $dt --opt 15=$o
+done; done; done 2>&1 | tee gpurun_out/combine_sweep.log
