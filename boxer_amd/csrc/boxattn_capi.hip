@@ -758,10 +758,12 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     // Chunked blocks: summed by their last chunk inside the accumulate launch (chunk_finish; the fill pass -- riding
     // or not -- clears the blocks' tickets) wherever the riders run: one launch less, C2 bf16 125.7 -> 122.9 us, C2 fp32
     // 245 -> 240, C2' fp32 420 -> 411 (profiles/r04_combine_sweep.log; with 1 024-record chunks and a spilling store
-    // path it had been the other way round at encoder sizes).  Maps too big for the riders (the BEV encoder) keep
-    // combine_partials_kernel behind the accumulate launch (C5' bf16 464 against 478 us).
+    // path it had been the other way round at encoder sizes) and for the short launch chains of few sample points.
+    // Encoder-sized maps too big for the riders (the BEV encoder) keep combine_partials_kernel behind the
+    // accumulate launch (C5' bf16 464 against 478 us).
+    const bool small = (long long)d.Lq * d.L * d.P < 65536;
     const bool own_combine = opt(kOptRiders) == 1 || opt(kOptRiders) == 2 ||
-                             (opt(kOptRiders) == 0 && !riders_ok(plan, pl));
+                             (opt(kOptRiders) == 0 && !riders_ok(plan, pl) && !small);
     if (!filled)
         launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinFill,
                        own_combine ? nullptr : (int *)(sbuf + sl.ctickets));

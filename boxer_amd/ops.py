@@ -137,14 +137,16 @@ def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
     return buf, sh, ls
 
 
-_STATE = {}          # (device index, stream handle) -> the library's persistent per-stream state buffer
+_STATE = {}          # (device index, stream handle, dims, dtype) -> the library's persistent state buffer
 
 
-def _state_buffer(device, stream, nbytes):
-    """The library's state buffer (include/boxattn.h, *_fwd_train_*: `state`): zeroed once, one per stream --
-    calls on one stream never overlap and every call leaves the tickets in it zero -- instead of a zero-fill
-    launch in front of every training forward; its tail holds the locality counters (_Locality)."""
-    key = (device.index, stream)
+def _state_buffer(key, device, nbytes):
+    """The library's state buffer (include/boxattn.h, *_fwd_train_*: `state`): zeroed once and kept -- calls on
+    one stream never overlap and every call leaves the tickets in it zero -- instead of a zero-fill launch in
+    front of every training forward.  One per (stream, shape): its first 1 KiB are the locality counters, and a
+    _Locality must only ever see the misses of ITS shape's calls (one buffer per stream, which the library would
+    be content with, let the counts of one test's uniformly random locations decide the kernels of the next
+    shape's first calls)."""
     buf = _STATE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
@@ -222,10 +224,13 @@ class _Locality:
 _LOCALITY = {}       # (device index, stream handle, dims) -> _Locality
 
 
-def _locality(value, stream, dims):
+def _shape_key(value, stream, dims):
+    return (value.device.index, stream, tuple(dims), value.dtype)
+
+
+def _locality(key):
     # (only the window-staged kernels of bf16 box attention with one query per pixel collect the counters;
     # everything else simply never sees a non-zero miss count)
-    key = (value.device.index, stream, tuple(dims), value.dtype)
     loc = _LOCALITY.get(key)
     if loc is None:
         loc = _LOCALITY[key] = _Locality()
@@ -241,8 +246,9 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
     with _device_guard(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
-        state = _state_buffer(value.device, stream, lib.boxattn_state_bytes(dims[0], dims[2]))
-        adapt = _locality(value, stream, dims)
+        key = _shape_key(value, stream, dims)
+        state = _state_buffer(key, value.device, lib.boxattn_state_bytes(dims[0], dims[2]))
+        adapt = _locality(key)
         hints = adapt.hints()
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, buf.data_ptr() if buf is not None else 0,
@@ -251,7 +257,8 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
         if rc == 0:
             adapt.after_call(state, hints)
     if rc != 0:
-        _STATE.pop((value.device.index, stream), None)      # (its tickets may not be zero any more)
+        _STATE.pop(key, None)                                # (its tickets may not be zero any more)
+        _LOCALITY.pop(key, None)
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
     return BackwardPlan(buf, _plan_key(dims, loc, weights), hints) if built.value else None
 

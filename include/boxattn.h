@@ -221,7 +221,8 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * calls of every shape on its stream)
  * that the window-staged forward of the encoder case only ever ADDS to: {sample points it had to fetch from
  * global memory because their footprint missed the staged window, sample points inside the window test}.  A
- * caller may read them whenever it likes (e.g. an asynchronous copy after a call; deltas between two reads)
+ * caller may read them whenever it likes (e.g. an asynchronous copy after a call; deltas between two reads; a
+ * caller that wants them per shape keeps one state buffer per shape and stream, as boxer_amd.ops does)
  * and, when most points miss -- sampling locations that are not local to their query, e.g. uniformly random
  * ones -- pass BOXATTN_HINT_NOT_LOCAL in `hints` of its next calls: forward and point gradients then run on
  * the row-gather kernels (same results; measured 14.5 against 12.8 Gpts/s on uniformly random locations,
@@ -345,8 +346,9 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *  15  riders: the count pass + scans inside the training forward's launch, the fill pass
  *      inside the point-gradient launch, chunked blocks summed inside the accumulate launch:
  *      0 default (on; chunked blocks are summed inside the accumulate launch wherever the riders run -- maps of up
- *      to 1 024 blocks per (image, head) -- and by a combine launch behind it otherwise), 1 off (launches of their
- *      own), 2 on with the combine always a launch of its own, 3 on with the combine always inside
+ *      to 1 024 blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head), and by a
+ *      combine launch behind it otherwise), 1 off (launches of their own), 2 on with the combine always a launch of
+ *      its own, 3 on with the combine always inside
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands
