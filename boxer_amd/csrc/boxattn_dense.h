@@ -7,7 +7,7 @@
 // position on every level, so the rows an 8x8 TILE of queries touches on one level form a small
 // window: 16x16 pixels on the tile's own level, 9x9 / 6x6 / 4x4 on the coarser ones -- 389 rows for
 // 64 queries x 64 corner rows.  One workgroup = one (tile, head): its four waves fetch the windows of
-// all levels once, as whole coalesced rows, into LDS (38 KB), and after ONE barrier every lane works
+// all levels once, as whole coalesced rows, straight into LDS (26 KB), and after ONE barrier every lane works
 // alone:
 //
 //   lane = one sample point of one query (wave = 4x4 sub-tile of queries x the 2x2 points), the

@@ -9,10 +9,12 @@
 //
 // The reference does its whole backward in one launch (box_attn_kernel.cuh:352-472, dispatch :1147-1200);
 // round 3 ran count -> forward -> fill -> accumulate -> point gradients back to back on one stream, the
-// two bin passes alone 13 + 25 us of a 143 us step.  The count / fill passes wait on memory (17 % issue
-// activity, 5 TB/s of record stores); the window-staged forward / point-gradient kernels are issue- and
-// LDS-bound: interleaved by workgroup index they share a CU's four workgroup slots and overlap where two
-// streams did not.
+// two bin passes alone 13 + 25 us of a 143 us step.  As riders they overlap with their host kernel's tiles
+// where two streams did not -- at a price: a rider has the host kernel's register / LDS footprint, so it
+// takes a tile workgroup's place for as long as it lives, and it is bound by VALU latency (one wave per
+// SIMD), not by memory.  FEW, FAT riders in front of the grid (one per CU, the next step's locations
+// always in flight) cost least: C2 bf16 step 146 / 139 / 135 / 154 us with 1 024 / 512 / 256 / 128
+// riders, 176 us interleaved with the tiles (profiles/r04_rider_sweep.log).
 //
 // Placement.  Rider workgroups come in GROUPS of 8 consecutive workgroup indices -- workgroup b runs on
 // XCD b % 8 (observed; only speed depends on it), so a group puts one rider on every XCD and the host
