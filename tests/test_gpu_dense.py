@@ -299,3 +299,31 @@ def test_kernel_choice_follows_the_data(monkeypatch, dense_switch):
     seen = steps(local, 8)                                      # same shape, local boxes now: a probe notices
     assert seen[-1] is False, seen
     assert state.ratio < ops._Locality.MISS_THRESHOLD, state.ratio
+
+
+def test_training_steps_on_two_streams_at_once(dense_switch):
+    """Two streams run training steps of the same shape concurrently (different inputs): every stream has its
+    own state buffer (tickets, counters), plan and backward scratch in boxer_amd.ops, so the riders' hand-offs of
+    one stream never see the other's -- results as on a single stream, step after step."""
+    from boxer_amd import ops
+    dense_switch(True)
+    levels = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    cases = [make_case(levels, "model", seed=31), make_case(levels, "mixed", seed=32)]
+    want = [run(c) for c in cases]                              # on the default stream, one after the other
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = [[], []]
+    for _ in range(12):
+        for i, (c, st) in enumerate(zip(cases, streams)):      # interleaved submission: the steps overlap on the GPU
+            with torch.cuda.stream(st):
+                v, sh, ls, loc, attn, go = (c[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
+                out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+                got[i].append((out,) + tuple(ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)))
+    torch.cuda.synchronize()
+    for i in range(2):
+        ref = (want[i][0],) + tuple(want[i][1])
+        for step in got[i]:
+            # out / grad_loc / grad_attn do not depend on any summation order; grad_value within the bf16 tolerance
+            assert torch.equal(step[0], ref[0]) and torch.equal(step[2], ref[2]) and torch.equal(step[3], ref[3])
+            err = (step[1].float() - ref[1].float()).abs().max().item()
+            assert err <= 1e-2 * max(1.0, ref[1].float().abs().max().item())
