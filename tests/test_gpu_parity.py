@@ -328,6 +328,24 @@ def test_block_scan_over_several_workgroups(levels):
             close(ga, want[2], torch.float32, "grad_attn")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_instance_backward_on_a_sparse_map(dtype):
+    """Instance attention on a map of more than 1 024 blocks with few queries (the mask decoder on a BEV-sized
+    map): a sparse plan -- no work items for the blocks without records, their zeros come from the zero workers
+    of the (VALU) accumulate kernel; into poisoned memory."""
+    g = _seeded([(136, 264), (17, 33)], 1, 2, 32, 40, 4, seed=33)
+    want = oc.instance_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["spatial_w"], g["level_w"],
+                                     g["grad_out"], g["grad_mask"])
+    junk = [torch.full(g["value"].shape, float("nan"), device="cuda", dtype=dtype) for _ in range(3)]
+    del junk
+    out, mask, gv, gl, gs, glw = run_inst(g, dtype, "binned")
+    assert torch.isfinite(gv.float()).all()
+    close(gv, want[0], dtype, "grad_value")
+    close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
+    close(gs, want[2], torch.float32, "grad_spatial")
+    close(glw, want[3], torch.float32, "grad_level")
+
+
 def test_binned_backward_clustered_points():
     """All sample points of a head on one pixel: one bin gets every record (many chunks),
     all other bins are empty."""
