@@ -23,9 +23,11 @@ constexpr int kDenseWinMax = 16;           // window rows / columns at most (one
 constexpr int kDenseSlotBytes = 64;        // one staged pixel: 32 bf16 channels
 constexpr int kDenseRowSkew = 16;          // bytes between the end of a window row and the start of the next
 #ifndef BOXATTN_DENSE_LDS
-#define BOXATTN_DENSE_LDS 26624
+#define BOXATTN_DENSE_LDS 28160
 #endif
-constexpr int kDenseLdsBytes = BOXATTN_DENSE_LDS;  // per workgroup (26 KB: six workgroups per CU; BoxeR-R50 tiles need 25.4)
+constexpr int kDenseLdsBytes = BOXATTN_DENSE_LDS;  // per workgroup: 27.5 KB -- five workgroups per CU also with the point-gradient
+                                                   // kernel's 4 KB stash (157.5 of 160 KB); BoxeR-R50 tiles need 25.4 KB,
+                                                   // odd map sizes (10 x 10 instead of 9 x 9 on the next level) 26.7
 constexpr int kDenseZeroOff = kDenseLdsBytes - kDenseSlotBytes;    // the forward's row of zeros (make_dense_plan leaves it free)
 constexpr int kDenseStatSlots = 64;        // pairs of 64-bit locality counters in the caller's state buffer (power of two)
 

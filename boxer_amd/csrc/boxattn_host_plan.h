@@ -242,13 +242,17 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
     // windows: a tile's queries sit at pixel coordinate (qx + 0.5) r - 0.5 of the sampled level
     // (r = W_l / W_lq); their points lie a quarter box (ref / 4 pixels of the query's level, i.e.
     // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further.
-    // The levels are staged coarsest first into the workgroup's kDenseLdsBytes of LDS; what does
-    // not fit (a coarse tile's window on a fine level) is not staged.
+    // The windows share the workgroup's kDenseLdsBytes of LDS; what does not fit (a coarse tile's window on a
+    // fine level) is not staged.
     const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
     const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
     for (int lq = 0; lq < d.L; ++lq) {
         int used = 0;
-        for (int l = d.L - 1; l >= 0; --l) {
+        // the tile's OWN level first -- its window serves the most points and must never be the one that does not
+        // fit (odd map sizes make the coarser windows a column or a row larger: 99 x 167 next to 50 x 84 is a ratio
+        // of 0.505, a 10 x 10 window instead of 9 x 9) -- then the others, coarsest first
+        for (int k = 0; k < d.L; ++k) {
+            const int l = k == 0 ? lq : (d.L - k <= lq ? d.L - k - 1 : d.L - k);
             DenseWin &w = p.win[lq][l];
             const float rx = (float)p.lv[l].W / (float)p.lv[lq].W, ry = (float)p.lv[l].H / (float)p.lv[lq].H;
             const float mx = rx * ref4 * (1.0f + jit), my = ry * ref4 * (1.0f + jit);
