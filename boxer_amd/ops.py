@@ -121,6 +121,16 @@ def _device_guard(device):
 
 
 _SIZES = {}          # (query name, is_bf16, dims, level tables) -> bytes: the size queries are pure functions
+_CACHE_CAP = 1024    # entries per shape-keyed cache: a detector trained on variably padded batches sees thousands of
+                     # shapes; everything cached per shape is cheap to rebuild
+
+
+def _bounded(cache):
+    """Shape-keyed caches start over instead of growing without bound (entries still referenced elsewhere -- a
+    state buffer a running kernel uses -- live on until the caching allocator gets them back, in stream order)."""
+    if len(cache) >= _CACHE_CAP:
+        cache.clear()
+    return cache
 
 
 def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
@@ -131,7 +141,7 @@ def _sized_buffer(query, value, shapes, lsi, dims, minimum=256):
     key = (query.__name__, is_bf16, dims, sh.tobytes(), ls.tobytes(), _lib.options_epoch())
     nbytes = _SIZES.get(key)
     if nbytes is None:
-        nbytes = _SIZES[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
+        nbytes = _bounded(_SIZES)[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
     nbytes = max(nbytes, minimum)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=value.device) if nbytes else None
     return buf, sh, ls
@@ -150,7 +160,7 @@ def _state_buffer(key, device, nbytes):
     buf = _STATE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
-        _STATE[key] = buf
+        _bounded(_STATE)[key] = buf
     return buf
 
 
@@ -233,7 +243,7 @@ def _locality(key):
     # everything else simply never sees a non-zero miss count)
     loc = _LOCALITY.get(key)
     if loc is None:
-        loc = _LOCALITY[key] = _Locality()
+        loc = _bounded(_LOCALITY)[key] = _Locality()
     return loc
 
 
@@ -284,7 +294,7 @@ def _workspace(query, value, shapes, lsi, dims, stream):
     key = (query.__name__, is_bf16, dims, sh.tobytes(), ls.tobytes(), _lib.options_epoch())
     nbytes = _SIZES.get(key)
     if nbytes is None:
-        nbytes = _SIZES[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
+        nbytes = _bounded(_SIZES)[key] = int(query(is_bf16, *dims, sh.ctypes.data, ls.ctypes.data))
     nbytes = max(nbytes, 256)
     wkey = (value.device.index, stream)
     ws = _WORKSPACE.get(wkey)
