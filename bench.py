@@ -180,14 +180,78 @@ def algorithmic_bytes(dims, kind, elem):
 # --------------------------------------------------------------------------------------
 # the timed step
 # --------------------------------------------------------------------------------------
+def reference_style_functions(mod):
+    """The reference's two autograd Functions, written as the reference writes them (box_attention_func.py:10-64,
+    83-150: forward saves the tensors and calls ``mod.*_forward``; backward calls ``mod.*_backward`` with nothing
+    but the saved tensors) on ``mod`` = a module with the four functions of ``e2edet.ops`` -- the compiled drop-in
+    (``boxer_amd._ext.load()``) or ``boxer_amd.ops``.  (No AMP decorators: the bench feeds the storage type directly.)"""
+    from torch.autograd import Function
+    from torch.autograd.function import once_differentiable
+
+    class RefBoxAttn(Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+            ctx.im2col_step = im2col_step
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return mod.box_attn_forward(value, shapes, lsi, loc, attn, im2col_step)
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = mod.box_attn_backward(value, shapes, lsi, loc, attn, grad_output.contiguous(),
+                                               ctx.im2col_step)
+            return gv, None, None, gl, ga, None
+
+    class RefInstanceAttn(Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, sw, lw, im2col_step):
+            ctx.im2col_step = im2col_step
+            ctx.save_for_backward(value, shapes, lsi, loc, sw, lw)
+            out, mask = mod.instance_attn_forward(value, shapes, lsi, loc, sw, lw, im2col_step)
+            return out, mask
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output, grad_mask):
+            value, shapes, lsi, loc, sw, lw = ctx.saved_tensors
+            gv, gl, gs, glw = mod.instance_attn_backward(value, shapes, lsi, loc, sw, lw, grad_output.contiguous(),
+                                                         grad_mask.contiguous(), ctx.im2col_step)
+            return gv, None, None, gl, gs, glw, None
+    return RefBoxAttn, RefInstanceAttn
+
+
 def make_step(inp, entry="ops"):
     """One training step of the operator.  entry "ops": the e2edet.ops boundary with the plan hand-over
     (``*_forward_train`` + ``*_backward(plan=...)``) -- what the autograd Functions call; entry "function":
     the drop-in Functions themselves (``BoxAttnFunction`` / ``BoxAttnBF16Function`` /
-    ``InstanceAttn*Function`` ``.apply`` + ``.backward``), i.e. what e2edet/module/box_attention.py:234 runs."""
+    ``InstanceAttn*Function`` ``.apply`` + ``.backward``), i.e. what e2edet/module/box_attention.py:234 runs;
+    entry "reference": Functions in the REFERENCE's own shape (reference_style_functions) on the compiled
+    drop-in module -- the four functions of e2edet.ops and nothing else."""
     from boxer_amd import ops
     v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn",
                                                   "grad_out"))
+    if entry == "reference":
+        from boxer_amd import _ext
+        torch.autograd.set_multithreading_enabled(False)       # (as for "function", see there)
+        ref_box, ref_inst = reference_style_functions(_ext.load())
+        vg, lg, ag = (t.detach().clone().requires_grad_() for t in (v, loc, attn))
+        if inp["kind"] == "box":
+            def step():
+                vg.grad = lg.grad = ag.grad = None
+                out = ref_box.apply(vg, sh, ls, lg, ag, 64)
+                out.backward(go)
+                return out, [vg.grad, lg.grad, ag.grad]
+        else:
+            wg = inp["level_w"].detach().clone().requires_grad_()
+            gm = inp["grad_mask"]
+
+            def step():
+                vg.grad = lg.grad = ag.grad = wg.grad = None
+                out, mask = ref_inst.apply(vg, sh, ls, lg, ag, wg, 64)
+                torch.autograd.backward([out, mask], [go, gm.view_as(mask)])
+                return (out, mask.view(gm.shape)), [vg.grad, lg.grad, ag.grad, wg.grad]
+        return step
     if entry == "function":
         import boxer_amd
         # One tiny autograd graph per step: with the engine's worker threads every step pays a cross-thread
@@ -515,6 +579,31 @@ def spawn_ranks(n, cmd=None):
     return rc
 
 
+def rotated_leg(args, dtype, device, rank, np_rank):
+    """The same step over N input / upstream-gradient sets cycled from step to step (inputs
+    regenerated outside the timed region).  The headline leg replays ONE resident set -- inputs, outputs and records
+    of a C2 step are ~250 MB, about the size of the 256 MiB Infinity Cache -- so its traffic is partly served on-die;
+    here consecutive steps share nothing but the level tables."""
+    sets = [make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch, seed=1000 * (rank + 1) + i)
+            for i in range(args.rotate)]
+    steps = [make_step(x, args.entry) for x in sets]
+    n = len(steps)
+    k = [0]
+
+    def step():
+        k[0] += 1
+        return steps[k[0] % n]()
+    n_timed = max(n, min(args.steps, 1000) // n * n)
+    elapsed = run_timed(step, n_timed, min(max(args.warmup, n), 4 * n), torch.cuda.synchronize, None, device)
+    value, ms = throughput(elapsed, np_rank, 1, n_timed)
+    foot = sum(t.numel() * t.element_size() for x in sets for t in x.values() if isinstance(t, torch.Tensor))
+    return {"sets": n, "steps": n_timed, "ms_per_step": round(ms, 4), "value": round(value, 4),
+            "unit": "Gsample-points/s", "input_footprint_MB": round(foot / 1e6, 1),
+            "note": "inputs and upstream gradients of consecutive steps are different tensors (N sets generated "
+                    "before the timed region); outputs / gradients are allocated per step by torch's caching "
+                    "allocator as in the headline leg"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,9 +614,13 @@ def main():
     ap.add_argument("--inputs", default="model", choices=["model", "test"])
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU (the headline line uses the default: 2; C1: 1)")
-    ap.add_argument("--entry", default="ops", choices=["ops", "function"],
-                    help="what a step calls: the e2edet.ops boundary with the plan hand-over (default) or the "
-                         "drop-in autograd Functions (.apply + .backward)")
+    ap.add_argument("--entry", default="ops", choices=["ops", "function", "reference"],
+                    help="what a step calls: the e2edet.ops boundary with the plan hand-over (default), the "
+                         "drop-in autograd Functions (.apply + .backward), or Functions in the reference's own shape "
+                         "on the compiled drop-in module (its four functions only)")
+    ap.add_argument("--rotate", type=int, default=8, metavar="N",
+                    help="second, cache-cold leg: N input / upstream-gradient sets (generated outside the timed "
+                         "region) cycled from step to step, reported as `rotated` (0: off)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a HIP graph and time replays (not the headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -596,6 +689,9 @@ def main():
 
     np_rank = n_points(inp["dims"])
     value, ms_per_step = throughput(elapsed, np_rank, world, args.steps)
+    rotated = None
+    if args.rotate > 1 and world == 1:
+        rotated = rotated_leg(args, dtype, device, rank, np_rank)
     per_rank = None
     if dist is not None:                   # per-rank spread (clock / power variance between GPUs)
         t0 = time.perf_counter()           # every rank alone, no barrier: its own rate
@@ -645,6 +741,8 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": dom_bytes,
                     "avg_launch_ms": round(dom_ms, 4), "timing": src,
+                    # the whole step against the roofline: north_star's ">= 60 %" is THIS number
+                    "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
                     "fwd_bwd": {"algorithmic_bytes": b_fwd + b_bwd,
                                 "achieved_GBs": round(step_gbs, 1),
                                 "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
@@ -658,9 +756,12 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "launch": "hip-graph replay" if args.graph else "eager",
-            "entry": ("boxer_amd.ops.*_forward_train + *_backward(plan=...) (the e2edet.ops boundary with the plan "
-                      "hand-over the Functions use)" if args.entry == "ops" else
-                      "autograd Function .apply + .backward (the reference's call site, box_attention.py:234)"),
+            "entry": {"ops": "boxer_amd.ops.*_forward_train + *_backward(plan=...) (the e2edet.ops boundary with the "
+                             "plan hand-over the Functions use)",
+                      "function": "autograd Function .apply + .backward (the reference's call site, "
+                                  "box_attention.py:234)",
+                      "reference": "Functions in the reference's own shape (box_attention_func.py:10-64) on the "
+                                   "compiled drop-in module: box_attn_forward / box_attn_backward only"}[args.entry],
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s-attn fwd+bwd, levels %s, Lq=%d, H=%d, C=%d, P=%d, "
                                    "B=%d images per GPU, inputs=%s" % (
@@ -675,6 +776,8 @@ def main():
                        "cell edge not compared)" % (PARITY_INFO.get("edge_points", -1), PARITY_INFO.get("points", -1))},
             "roofline": roofline,
         }
+        if rotated is not None:
+            line["rotated"] = rotated
         if per_rank is not None:
             line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:

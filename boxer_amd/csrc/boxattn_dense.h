@@ -431,7 +431,11 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     // (the attention weights are needed last, for the location gradients: parked in a lane-private piece of LDS
     // meanwhile -- held in registers the kernel does not fit five waves per SIMD, and the compiler's own spill
     // goes to scratch with a full memory wait per value)
-    volatile float *a_stash = reinterpret_cast<volatile float *>(win_lds + kDenseLdsBytes) + 4 * threadIdx.x;
+    // (an LDS pointer BY TYPE: address spaces are not inferred for volatile accesses -- through a generic pointer these
+    // were flat stores / loads with system scope, each followed by s_waitcnt vmcnt(0): four serialised round trips in
+    // front of the barrier, with every window row and operand load of the wave still in flight)
+    typedef __attribute__((address_space(3))) float dense_lds_float;
+    volatile dense_lds_float *a_stash = (volatile dense_lds_float *)(win_lds + kDenseLdsBytes) + 4 * threadIdx.x;
     if (BOXATTN_TUNE_PG_STASH) {
 #pragma unroll
         for (int l = 0; l < L; ++l) a_stash[l] = a[l];

@@ -19,6 +19,11 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "boxattn.h"
@@ -90,20 +95,134 @@ void *current_stream(const at::Tensor &t)
     return (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
 }
 
-// Host copies of the two level tables (a few int64 each); the workspace entry points want them.
+// ---- what a training step must not pay for on every call (boxer_amd/ops.py keeps the same three things):
+//  * host copies of the two level tables: one device -> host copy (a synchronisation) per TENSOR, not per call --
+//    BoxeR hands the same two tensors to every layer of every step;
+//  * the backward's scratch: one tensor per (device, stream), grown as needed (0.1-0.3 GB at BoxeR-R50 shapes);
+//  * the plan: a forward whose inputs require a gradient runs the *_fwd_train_* entry and PARKS the plan; the
+//    backward -- which the reference's Function calls with nothing but the saved tensors
+//    (box_attention_func.py:24-64) -- finds it under (stream, dimensions, location / weight addresses + versions).
+std::mutex g_mu;
+
+struct TableEntry {
+    c10::weak_intrusive_ptr<c10::TensorImpl> impl;     // the tensor object the copy was made of ...
+    uint32_t version;                                  // ... and its version counter then
+    std::shared_ptr<const std::vector<int64_t>> data;
+};
+std::map<const c10::TensorImpl *, TableEntry> g_tables;
+constexpr size_t kTableCap = 64;
+
+uint32_t version_of(const at::Tensor &t)
+{
+    return t.is_inference() ? 0u : (uint32_t)t._version();
+}
+
+// Host copy of a small int64 device table, cached on the tensor OBJECT: an address alone may be a new tensor's (the
+// weak reference tells a live object from a recycled address), a version tells an in-place update.
+std::shared_ptr<const std::vector<int64_t>> host_table(const at::Tensor &t)
+{
+    const c10::TensorImpl *key = t.unsafeGetTensorImpl();
+    const uint32_t ver = version_of(t);
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        const auto it = g_tables.find(key);
+        if (it != g_tables.end()) {
+            const auto alive = it->second.impl.lock();
+            if (alive && alive.get() == key && it->second.version == ver) return it->second.data;
+            g_tables.erase(it);
+        }
+    }
+    const at::Tensor h = t.cpu().contiguous();         // (the one synchronising copy)
+    auto data = std::make_shared<const std::vector<int64_t>>(h.data_ptr<int64_t>(), h.data_ptr<int64_t>() + h.numel());
+    std::lock_guard<std::mutex> g(g_mu);
+    if (g_tables.size() >= kTableCap) g_tables.clear();
+    g_tables.erase(key);
+    g_tables.emplace(key, TableEntry{c10::weak_intrusive_ptr<c10::TensorImpl>(t.getIntrusivePtr()), ver, data});
+    return data;
+}
 struct HostTables {
-    at::Tensor shapes, lsi;
-    HostTables(const at::Tensor &s, const at::Tensor &l)
-        : shapes(s.cpu().contiguous()), lsi(l.cpu().contiguous()) {}
-    const int64_t *sh() const { return shapes.data_ptr<int64_t>(); }
-    const int64_t *ls() const { return lsi.data_ptr<int64_t>(); }
+    std::shared_ptr<const std::vector<int64_t>> shapes, lsi;
+    HostTables(const at::Tensor &s, const at::Tensor &l) : shapes(host_table(s)), lsi(host_table(l)) {}
+    const int64_t *sh() const { return shapes->data(); }
+    const int64_t *ls() const { return lsi->data(); }
 };
 
-at::Tensor workspace(const at::Tensor &value, const Dims &d, const HostTables &h)
+typedef std::pair<int, void *> StreamKey;               // (device index, stream handle)
+std::map<StreamKey, at::Tensor> g_workspace, g_state;
+
+// the backward's scratch of this stream (contents only live inside one call; calls on a stream never overlap)
+at::Tensor workspace(const at::Tensor &value, const Dims &d, const HostTables &h, void *stream)
 {
-    const size_t bytes = boxattn_bwd_workspace_bytes(value.scalar_type() == at::kBFloat16, d.B, d.S,
-                                                     d.H, d.C, d.L, d.Lq, d.P, h.sh(), h.ls());
-    return at::empty({(int64_t)std::max<size_t>(bytes, 256)}, value.options().dtype(at::kByte));
+    const size_t bytes = std::max<size_t>(
+        boxattn_bwd_workspace_bytes(value.scalar_type() == at::kBFloat16, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
+                                    h.sh(), h.ls()), 256);
+    const StreamKey key(value.get_device(), stream);
+    std::lock_guard<std::mutex> g(g_mu);
+    at::Tensor &ws = g_workspace[key];
+    if (!ws.defined() || (size_t)ws.numel() < bytes)
+        ws = at::empty({(int64_t)bytes}, value.options().dtype(at::kByte));
+    return ws;
+}
+// the library's state buffer of this stream: zeroed once, every call leaves its tickets zero
+at::Tensor state(const at::Tensor &value, const Dims &d, void *stream)
+{
+    const size_t bytes = boxattn_state_bytes(d.B, d.H);
+    const StreamKey key(value.get_device(), stream);
+    std::lock_guard<std::mutex> g(g_mu);
+    at::Tensor &st = g_state[key];
+    if (!st.defined() || (size_t)st.numel() < bytes)
+        st = at::zeros({(int64_t)bytes}, value.options().dtype(at::kByte));
+    return st;
+}
+
+// ---- parked plans
+typedef std::tuple<int, void *, int, int, int, int, int, int, int, int, const void *, uint32_t, const void *, uint32_t,
+                   const void *, uint32_t> PlanKey;
+struct Parked {
+    PlanKey key;
+    at::Tensor plan;
+    std::vector<at::Tensor> keep;      // the tensors the key names: held, so that their addresses stay theirs
+};
+std::deque<Parked> g_parked;
+constexpr size_t kParkCap = 32;
+
+PlanKey plan_key(const at::Tensor &value, void *stream, const Dims &d, const at::Tensor &loc, const at::Tensor &w0,
+                 const at::Tensor *w1)
+{
+    return PlanKey(value.get_device(), stream, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, boxattn_options_epoch(),
+                   loc.data_ptr(), version_of(loc), w0.data_ptr(), version_of(w0), w1 ? w1->data_ptr() : nullptr,
+                   w1 ? version_of(*w1) : 0u);
+}
+void park(PlanKey key, at::Tensor plan, std::vector<at::Tensor> keep)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    for (auto it = g_parked.begin(); it != g_parked.end();)
+        it = it->key == key ? g_parked.erase(it) : it + 1;
+    while (g_parked.size() >= kParkCap) g_parked.pop_front();
+    g_parked.push_back(Parked{key, std::move(plan), std::move(keep)});
+}
+at::Tensor take_parked(const PlanKey &key)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    for (auto it = g_parked.begin(); it != g_parked.end(); ++it)
+        if (it->key == key) {
+            at::Tensor plan = it->plan;
+            g_parked.erase(it);
+            return plan;
+        }
+    return at::Tensor();
+}
+bool wants_plan(std::initializer_list<const at::Tensor *> ts)
+{
+    for (const at::Tensor *t : ts)
+        if (t->requires_grad()) return true;
+    return false;
+}
+at::Tensor plan_buffer(const at::Tensor &value, const Dims &d, const HostTables &h)
+{
+    const size_t bytes = boxattn_plan_bytes(value.scalar_type() == at::kBFloat16, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
+                                            h.sh(), h.ls());
+    return bytes ? at::empty({(int64_t)bytes}, value.options().dtype(at::kByte)) : at::Tensor();
 }
 
 const uint16_t *bf(const at::Tensor &t) { return (const uint16_t *)t.data_ptr(); }
@@ -129,7 +248,24 @@ at::Tensor box_attn_forward(const at::Tensor &value, const at::Tensor &spatial_s
                              out.data_ptr<double>(), st);
     } else {
         const HostTables h(spatial_shapes, level_start_index);
-        if (value.scalar_type() == at::kFloat)
+        at::Tensor plan;
+        if (wants_plan({&value, &sampling_loc, &attn_weight})) plan = plan_buffer(value, d, h);
+        if (plan.defined()) {          // a backward will follow: the forward's launch prepares its plan
+            at::Tensor state_buf = state(value, d, st);
+            int built = 0;
+            if (value.scalar_type() == at::kFloat)
+                rc = boxattn_fwd_train_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
+                                           attn_weight.data_ptr<float>(), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
+                                           out.data_ptr<float>(), h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(),
+                                           state_buf.data_ptr(), (size_t)state_buf.numel(), 0, &built, st);
+            else
+                rc = boxattn_fwd_train_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
+                                            attn_weight.data_ptr<float>(), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, bf(out),
+                                            h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(), state_buf.data_ptr(),
+                                            (size_t)state_buf.numel(), 0, &built, st);
+            if (rc == 0 && built)
+                park(plan_key(value, st, d, sampling_loc, attn_weight, nullptr), plan, {sampling_loc, attn_weight});
+        } else if (value.scalar_type() == at::kFloat)
             rc = boxattn_fwd_hl_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
                                     attn_weight.data_ptr<float>(), d.B, d.S, d.H, d.C, d.L, d.Lq,
                                     d.P, out.data_ptr<float>(), h.sh(), h.ls(), st);
@@ -171,19 +307,22 @@ std::vector<at::Tensor> box_attn_backward(const at::Tensor &value, const at::Ten
                              grad_loc.data_ptr<double>(), grad_attn.data_ptr<double>(), st);
     } else {
         const HostTables h(spatial_shapes, level_start_index);
-        at::Tensor ws = workspace(value, d, h);
+        at::Tensor ws = workspace(value, d, h, st);
+        const at::Tensor plan = take_parked(plan_key(value, st, d, sampling_loc, attn_weight, nullptr));
+        const void *pp = plan.defined() ? plan.data_ptr() : nullptr;
+        const size_t pn = plan.defined() ? (size_t)plan.numel() : 0;
         if (value.scalar_type() == at::kFloat)
             rc = boxattn_bwd_ws_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
                                     attn_weight.data_ptr<float>(), grad_output.data_ptr<float>(),
                                     d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(),
                                     grad_loc.data_ptr<float>(), grad_attn.data_ptr<float>(), h.sh(),
-                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, 0, st);
+                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn, 0, st);
         else
             rc = boxattn_bwd_ws_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                                      attn_weight.data_ptr<float>(), bf(grad_output), d.B, d.S, d.H,
                                      d.C, d.L, d.Lq, d.P, bf(grad_value), grad_loc.data_ptr<float>(),
                                      grad_attn.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                                     (size_t)ws.numel(), nullptr, 0, 0, st);
+                                     (size_t)ws.numel(), pp, pn, 0, st);
     }
     check_rc(rc, "boxattn_bwd");
     return {grad_value, grad_loc, grad_attn};
@@ -206,6 +345,33 @@ std::vector<at::Tensor> instance_attn_forward(const at::Tensor &value,
     const int64_t *sh = spatial_shapes.data_ptr<int64_t>(), *ls = level_start_index.data_ptr<int64_t>();
     void *st = current_stream(value);
     int rc;
+    at::Tensor plan;
+    if (value.scalar_type() != at::kDouble &&
+        wants_plan({&value, &sampling_loc, &spatial_attn_weight, &level_attn_weight})) {
+        const HostTables h(spatial_shapes, level_start_index);
+        plan = plan_buffer(value, d, h);
+        if (plan.defined()) {
+            at::Tensor state_buf = state(value, d, st);
+            int built = 0;
+            if (value.scalar_type() == at::kFloat)
+                rc = instattn_fwd_train_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
+                                            spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
+                                            d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, out.data_ptr<float>(),
+                                            mask.data_ptr<float>(), h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(),
+                                            state_buf.data_ptr(), (size_t)state_buf.numel(), 0, &built, st);
+            else
+                rc = instattn_fwd_train_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
+                                             spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
+                                             d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, bf(out), bf(mask), h.sh(), h.ls(),
+                                             plan.data_ptr(), (size_t)plan.numel(), state_buf.data_ptr(),
+                                             (size_t)state_buf.numel(), 0, &built, st);
+            if (rc == 0 && built)
+                park(plan_key(value, st, d, sampling_loc, spatial_attn_weight, &level_attn_weight), plan,
+                     {sampling_loc, spatial_attn_weight, level_attn_weight});
+            check_rc(rc, "instattn_fwd");
+            return {out, mask};
+        }
+    }
     if (value.scalar_type() == at::kDouble)
         rc = instattn_fwd_f64(value.data_ptr<double>(), sh, ls, sampling_loc.data_ptr<double>(),
                               spatial_attn_weight.data_ptr<double>(),
@@ -260,7 +426,11 @@ std::vector<at::Tensor> instance_attn_backward(
                               grad_sw.data_ptr<double>(), grad_lw.data_ptr<double>(), st);
     } else {
         const HostTables h(spatial_shapes, level_start_index);
-        at::Tensor ws = workspace(value, d, h);
+        at::Tensor ws = workspace(value, d, h, st);
+        const at::Tensor plan =
+            take_parked(plan_key(value, st, d, sampling_loc, spatial_attn_weight, &level_attn_weight));
+        const void *pp = plan.defined() ? plan.data_ptr() : nullptr;
+        const size_t pn = plan.defined() ? (size_t)plan.numel() : 0;
         if (value.scalar_type() == at::kFloat)
             rc = instattn_bwd_ws_f32(
                 value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
@@ -268,14 +438,14 @@ std::vector<at::Tensor> instance_attn_backward(
                 grad_output.data_ptr<float>(), grad_mask_output.data_ptr<float>(), d.B, d.S, d.H,
                 d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(), grad_loc.data_ptr<float>(),
                 grad_sw.data_ptr<float>(), grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                (size_t)ws.numel(), nullptr, 0, 0, st);
+                (size_t)ws.numel(), pp, pn, 0, st);
         else
             rc = instattn_bwd_ws_bf16(
                 bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                 spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
                 bf(grad_output), bf(grad_mask_output), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
                 bf(grad_value), grad_loc.data_ptr<float>(), grad_sw.data_ptr<float>(),
-                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), nullptr, 0, 0, st);
+                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn, 0, st);
     }
     check_rc(rc, "instattn_bwd");
     return {grad_value, grad_loc, grad_sw, grad_lw};
@@ -288,6 +458,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("instance_attn_forward", &instance_attn_forward, "instance_attn_forward");
     m.def("instance_attn_backward", &instance_attn_backward, "instance_attn_backward");
     m.def("abi_version", &boxattn_abi_version, "ABI version of the linked libboxattn_hip.so");
+    m.def("parked_plans", []() { std::lock_guard<std::mutex> g(g_mu); return (int)g_parked.size(); },
+          "plans parked by training forwards whose backward has not run yet");
+    m.def("release_buffers", []() {
+        std::lock_guard<std::mutex> g(g_mu);
+        g_parked.clear(); g_workspace.clear(); g_state.clear(); g_tables.clear();
+    }, "drop the cached scratch / state tensors, host tables and parked plans");
     m.attr("compiled_abi_version") = BOXATTN_ABI_VERSION;      // of the header this module was compiled against
 }
 

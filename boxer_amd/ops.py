@@ -12,6 +12,8 @@ Beyond the reference: ``value`` (and the upstream gradients) may be bfloat16; sa
 locations and attention weights are then taken in float32 (bf16 ones are upcast) and all
 accumulation is float32.  float32 / float64 calls behave exactly like the reference.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -92,15 +94,18 @@ class BackwardPlan:
     which the forward's launch already counted and scanned the sample points' destination bins (the
     binning only depends on the sampling locations), plus what it is valid for."""
 
-    __slots__ = ("buf", "key", "hints")
+    __slots__ = ("buf", "key", "hints", "keep")
 
     def __init__(self, buf, key, hints=0):
         self.buf, self.key, self.hints = buf, key, hints       # hints: as the forward ran (BOXATTN_HINT_*)
+        self.keep = None                                       # parked plans: the tensors the key names (see _park)
 
 
 def _plan_key(dims, loc, weights):
-    return (tuple(dims), loc.device.index) + tuple((t.data_ptr(), t._version)
-                                                    for t in (loc,) + tuple(weights))
+    # (the library's option switches -- records per item, riders, accumulate flavour, variant -- change the plan's
+    # layout: a plan built under other settings is not this call's plan)
+    return (tuple(dims), loc.device.index, _lib.options_epoch()) + tuple((t.data_ptr(), t._version)
+                                                                         for t in (loc,) + tuple(weights))
 
 
 class _NoGuard:
@@ -160,7 +165,10 @@ def _state_buffer(key, device, nbytes):
     buf = _STATE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
-        _bounded(_STATE)[key] = buf
+        # (a tensor first created while the stream captures a graph lives in the graph's private pool: it serves
+        # this call -- the graph keeps it alive -- but must not outlive the graph in this table)
+        if not torch.cuda.is_current_stream_capturing():
+            _bounded(_STATE)[key] = buf
     return buf
 
 
@@ -190,9 +198,13 @@ class _Locality:
     READ_EVERY = 16                  # staged calls between two reads of the counters
 
     def hints(self):
-        if self.pending is not None and self.event.query():
+        # (nothing here touches an event while the stream is capturing a graph: querying one from the capturing
+        # thread is not a capture-safe call; the last decision stands)
+        if self.pending is not None and not torch.cuda.is_current_stream_capturing() and self.event.query():
             now = self.host.view(-1, 2).sum(0)
             self.pending = None
+            # the FIRST read is the baseline (a state buffer that served an earlier _Locality of this shape carries
+            # that one's counts); decisions from the second read on
             if self.last is not None:
                 d_miss, d_all = int(now[0] - self.last[0]), int(now[1] - self.last[1])
                 if d_all > 0:
@@ -223,7 +235,6 @@ class _Locality:
         if self.host is None:
             self.host = torch.empty(128, dtype=torch.int64, pin_memory=True)
             self.event = torch.cuda.Event()
-            self.last = torch.zeros(2, dtype=torch.int64)      # counters before the first call: the baseline
         self.host.copy_(state[:1024].view(torch.int64), non_blocking=True)   # the counters: the buffer's first 1 KiB
         self.event.record()
         self.pending = True
@@ -299,15 +310,90 @@ def _workspace(query, value, shapes, lsi, dims, stream):
     wkey = (value.device.index, stream)
     ws = _WORKSPACE.get(wkey)
     if ws is None or ws.numel() < nbytes:
-        ws = _WORKSPACE[wkey] = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+        # cached per (device, stream) unless the caller opted out (set_workspace_caching(False): the scratch is then
+        # transient inside each backward, as in rounds 1-3) or the stream is capturing a graph (private pool)
+        if _CACHE_WORKSPACE and not torch.cuda.is_current_stream_capturing():
+            if len(_WORKSPACE) >= _WORKSPACE_CAP:          # streams come and go: start over rather than grow
+                _WORKSPACE.clear()
+            _WORKSPACE[wkey] = ws
     return ws, sh, ls
 
 
+_CACHE_WORKSPACE = os.environ.get("BOXATTN_CACHE_WORKSPACE", "1") != "0"
+_WORKSPACE_CAP = 64
+
+
+def set_workspace_caching(on):
+    """Keep the backward's scratch (0.1-0.3 GB at BoxeR-R50 shapes) per (device, stream) for the life of the process
+    (default: saves a torch.empty per backward, ~10 % of a step's host time) or allocate it inside every backward
+    (off: it is then not resident during the forward, i.e. not part of the step's peak activation memory).
+    Environment: BOXATTN_CACHE_WORKSPACE=0."""
+    global _CACHE_WORKSPACE
+    _CACHE_WORKSPACE = bool(on)
+    if not on:
+        _WORKSPACE.clear()
+
+
 def release_workspaces():
-    """Drop the cached scratch / state tensors (they are re-created on demand)."""
+    """Drop the cached scratch / state tensors and parked plans (they are re-created on demand)."""
     _WORKSPACE.clear()
     _STATE.clear()
     _LOCALITY.clear()
+    _PARKED.clear()
+
+
+# ---------------------------------------------------------------------------------------
+# The reference's own four-function API with the training step's fast path.
+#
+# BoxeR's Functions call box_attn_forward, then -- in another call, with nothing but the saved tensors --
+# box_attn_backward (box_attention_func.py:10-64).  When an input of the forward requires a gradient (the
+# tensors keep that flag inside a Function's forward) the forward runs the *_fwd_train_* entry and PARKS the
+# plan under (stream, dimensions, location / weight tensors' addresses and versions); the matching backward
+# finds it there.  A backward without a parked plan plans for itself, as ever.  Bounded: a forward whose
+# backward never comes (evaluation under enable_grad, a crashed step) is evicted, oldest first.
+# ---------------------------------------------------------------------------------------
+_PARKED = {}         # (device, stream handle, plan key) -> BackwardPlan, insertion-ordered
+_PARK_CAP = 32       # plans alive between forward and backward: layers of a model x micro-batches
+_PARK_PLANS = os.environ.get("BOXATTN_PARK_PLANS", "1") != "0"
+
+
+def set_plan_parking(on):
+    """box_attn_forward / instance_attn_forward called with inputs that require a gradient build the backward's plan
+    and park it for the matching *_backward call (default) -- or do not (off: every forward is an inference forward,
+    every backward plans for itself).  Environment: BOXATTN_PARK_PLANS=0."""
+    global _PARK_PLANS
+    _PARK_PLANS = bool(on)
+    if not on:
+        _PARKED.clear()
+
+
+def _wants_plan(*tensors):
+    return _PARK_PLANS and any(t.requires_grad for t in tensors)
+
+
+def _park(value, plan, keep):
+    if plan is None:
+        return
+    # The key names the location / weight tensors by address and version.  A parked plan HOLDS them: as long as it is
+    # parked their memory cannot be freed and handed to another tensor, so a backward that presents the same
+    # addresses and versions presents the same data.  (A plan handed over explicitly needs no such hold: the
+    # Function's context keeps the tensors.)
+    plan.keep = keep
+    stream = torch.cuda.current_stream(value.device).cuda_stream
+    while len(_PARKED) >= _PARK_CAP:
+        _PARKED.pop(next(iter(_PARKED)))
+    _PARKED[(value.device.index, stream) + plan.key] = plan
+
+
+def _parked(value, dims, loc, weights):
+    if not _PARKED:
+        return None
+    stream = torch.cuda.current_stream(value.device).cuda_stream
+    plan = _PARKED.pop((value.device.index, stream) + _plan_key(dims, loc, weights), None)
+    if plan is not None:
+        plan.keep = None
+    return plan
 
 
 def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
@@ -345,6 +431,10 @@ def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, att
     out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
     if value.dtype == torch.float64:
         _call("boxattn_fwd", value, value, spatial_shapes, level_start_index, loc, attn, *dims, out)
+    elif _wants_plan(value, sampling_loc, attn_weight):      # a backward will follow: build and park its plan
+        _park(value, _forward_train("boxattn_fwd_train", value, spatial_shapes, level_start_index, loc,
+                                    (attn,), dims,
+                                    [value, spatial_shapes, level_start_index, loc, attn, *dims, out]), (loc, attn))
     else:       # host copies of the level tables let the library recognise the encoder case
         sh, ls = _host_table(spatial_shapes), _host_table(level_start_index)
         _call("boxattn_fwd_hl", value, value, spatial_shapes, level_start_index, loc, attn, *dims,
@@ -389,6 +479,8 @@ def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, at
     if value.dtype == torch.float64:
         _call("boxattn_bwd", value, *args)
     else:
+        if plan is None:
+            plan = _parked(value, dims, loc, (attn,))
         _backward_with_workspace("boxattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
                                  (attn,), dims, args, plan)
     return [grad_value, grad_loc, grad_attn]
@@ -403,8 +495,14 @@ def instance_attn_forward(value, spatial_shapes, level_start_index, sampling_loc
     _chunk_assert(B, im2col_step)
     out = torch.empty((B, Lq, H * C), dtype=value.dtype, device=value.device)
     mask = torch.empty((B, Lq, P, H * C), dtype=value.dtype, device=value.device)
-    _call("instattn_fwd", value, value, spatial_shapes, level_start_index, loc, sw, lw, *dims,
-          out, mask)
+    if value.dtype != torch.float64 and _wants_plan(value, sampling_loc, spatial_attn_weight, level_attn_weight):
+        _park(value, _forward_train("instattn_fwd_train", value, spatial_shapes, level_start_index, loc,
+                                    (sw, lw), dims,
+                                    [value, spatial_shapes, level_start_index, loc, sw, lw, *dims, out, mask]),
+              (loc, sw, lw))
+    else:
+        _call("instattn_fwd", value, value, spatial_shapes, level_start_index, loc, sw, lw, *dims,
+              out, mask)
     return [out, mask]
 
 
@@ -448,6 +546,8 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
     if value.dtype == torch.float64:
         _call("instattn_bwd", value, *args)
     else:
+        if plan is None:
+            plan = _parked(value, dims, loc, (sw, lw))
         _backward_with_workspace("instattn_bwd_ws", value, spatial_shapes, level_start_index, loc,
                                  (sw, lw), dims, args, plan)
     return [grad_value, grad_loc, grad_sw, grad_lw]

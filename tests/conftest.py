@@ -37,4 +37,5 @@ def _fresh_kernel_choice():
     ops = sys.modules.get("boxer_amd.ops")
     if ops is not None:
         ops._LOCALITY.clear()
+        ops._PARKED.clear()          # (plans parked by a forward whose backward a test never ran)
     yield

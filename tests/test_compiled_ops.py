@@ -177,6 +177,53 @@ def test_reference_style_function_on_the_compiled_module(compiled):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["box", "instance"])
+def test_reference_style_functions_get_the_parked_plan(compiled, dtype, kind):
+    """Functions in the reference's own shape (bench.reference_style_functions: forward calls ``_C.*_forward``,
+    backward calls ``_C.*_backward`` with the saved tensors only -- box_attention_func.py:10-150) on the compiled
+    module: the forward parks the plan its launch prepared, the backward takes it -- no count / scan launches in the
+    backward (the library's "bwd_binning" timing slot stays empty) -- and the gradients are the golden ones.
+    Without gradient requirements nothing is parked; the module caches the host level tables per tensor object and
+    one scratch tensor per stream (no device -> host copy and no allocation per call)."""
+    import bench
+    from boxer_amd import _lib
+    g = golden_io.load("G6_box_ml" if kind == "box" else "G6_inst_ms4")    # (inputs exact in bf16)
+    compiled.release_buffers()
+    ref_box, ref_inst = bench.reference_style_functions(compiled)
+    cdt = torch.float32
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    v = _dev(g["value"], dtype).requires_grad_()
+    l = _dev(g["loc"], cdt).requires_grad_()
+    tol = TOL[dtype]
+    _lib.profile_begin()
+    try:
+        if kind == "box":
+            a = _dev(g["attn"], cdt).requires_grad_()
+            out = ref_box.apply(v, shapes, lsi, l, a, 64)
+            assert compiled.parked_plans() == 1
+            out.backward(_dev(g["grad_out"], dtype))
+        else:
+            sw, lw = _dev(g["spatial_w"], cdt).requires_grad_(), _dev(g["level_w"], cdt).requires_grad_()
+            out, mask = ref_inst.apply(v, shapes, lsi, l, sw, lw, 64)
+            assert compiled.parked_plans() == 1
+            torch.autograd.backward([out, mask], [_dev(g["grad_out"], dtype),
+                                                  _dev(g["grad_mask"], dtype).reshape(mask.shape)])
+        torch.cuda.synchronize()
+    finally:
+        slots = _lib.profile_end()
+    assert compiled.parked_plans() == 0
+    assert slots["bwd_binning"]["launches"] == 0, slots
+    _close(out, g["out"], tol, "out")
+    _close(v.grad, g["grad_value"], tol, "grad_value")
+    if kind == "box":
+        _close(a.grad, g["grad_attn"], max(tol, 1e-4), "grad_attn")
+        with torch.no_grad():          # nothing requires a gradient: an inference forward, nothing parked
+            compiled.box_attn_forward(v.detach(), shapes, lsi, l.detach(), a.detach(), 64)
+        assert compiled.parked_plans() == 0
+
+
+@pytest.mark.gpu
 def test_runs_on_the_current_stream(compiled):
     """The module launches on torch's CURRENT stream of the tensors' device (c10's stream guard):
     work queued on a side stream behind a long-running kernel must see that kernel's result."""

@@ -923,6 +923,113 @@ def test_training_forward_plan(dtype):
     close(gv3, want3[0], dtype, "grad_value (plan with stale weights ignored)")
 
 
+def _ref_style_function(mod):
+    """An autograd Function in the reference's own shape (box_attention_func.py:10-64): forward saves the five
+    tensors and calls ``box_attn_forward``; backward calls ``box_attn_backward`` with nothing but them."""
+    from torch.autograd import Function
+    from torch.autograd.function import once_differentiable
+
+    class RefStyleBoxAttn(Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+            ctx.im2col_step = im2col_step
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return mod.box_attn_forward(value, shapes, lsi, loc, attn, im2col_step)
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = mod.box_attn_backward(value, shapes, lsi, loc, attn, grad_output.contiguous(),
+                                               ctx.im2col_step)
+            return gv, None, None, gl, ga, None
+    return RefStyleBoxAttn
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_api_parks_the_plan(dtype):
+    """The reference's four-function API gets the training step's fast path: a ``box_attn_forward`` whose inputs
+    require a gradient builds the backward's plan and parks it; the ``box_attn_backward`` that follows -- called, as
+    the reference's Function calls it, with the saved tensors only -- finds it: NO count / scan launches in the
+    backward (the library's "bwd_binning" timing slot stays empty), same gradients as the oracle's.  A forward
+    without gradient requirements parks nothing, and a backward that finds nothing plans for itself."""
+    from boxer_amd import _lib, ops
+    g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=47)
+    cdt = _cdt(dtype)
+    shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])
+    fn = _ref_style_function(ops)
+
+    def step(requires_grad):
+        v = dev(g["value"], dtype).requires_grad_(requires_grad)
+        l = dev(g["loc"], cdt).requires_grad_(requires_grad)
+        a = dev(g["attn"], cdt).requires_grad_(requires_grad)
+        _lib.profile_begin()
+        try:
+            if requires_grad:
+                out = fn.apply(v, shapes, lsi, l, a, 64)
+                parked = len(ops._PARKED)
+                out.backward(dev(g["grad_out"], dtype))
+                grads = (v.grad, l.grad, a.grad)
+            else:
+                ops.box_attn_forward(v, shapes, lsi, l, a, 64)
+                parked = len(ops._PARKED)
+                grads = ops.box_attn_backward(v, shapes, lsi, l, a, dev(g["grad_out"], dtype), 64)
+            torch.cuda.synchronize()
+        finally:
+            slots = _lib.profile_end()
+        return grads, parked, slots
+
+    grads, parked, slots = step(True)
+    assert parked == 1 and len(ops._PARKED) == 0, "forward parks one plan, the backward takes it"
+    assert slots["bwd_binning"]["launches"] == 0, slots
+    close(grads[0], want[0], dtype, "grad_value (parked plan)")
+    close(grads[1], want[1], torch.float32, "grad_loc (parked plan)", ignore=g["on_edge"])
+    close(grads[2], want[2], torch.float32, "grad_attn (parked plan)")
+    grads, parked, slots = step(False)
+    assert parked == 0
+    assert slots["bwd_binning"]["launches"] > 0, "no plan: the backward counts and scans itself"
+    close(grads[0], want[0], dtype, "grad_value (own plan)")
+    old = ops._PARK_PLANS
+    ops.set_plan_parking(False)
+    try:
+        _, parked, slots = step(True)
+        assert parked == 0 and slots["bwd_binning"]["launches"] > 0
+    finally:
+        ops.set_plan_parking(old)
+
+
+def test_parked_plan_is_not_taken_by_other_tensors():
+    """A parked plan names its location / weight tensors by address and version and holds them while it is parked:
+    a backward with OTHER tensors of the same shape -- whatever their addresses -- must not get it, and a backward
+    after an in-place update of the locations must not either."""
+    from boxer_amd import ops
+    g = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 300, 4, seed=53)
+    shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
+    v = dev(g["value"], torch.float32).requires_grad_()
+    l = dev(g["loc"], torch.float32).requires_grad_()
+    a = dev(g["attn"], torch.float32).requires_grad_()
+    gout = dev(g["grad_out"], torch.float32)
+    ops.box_attn_forward(v, shapes, lsi, l, a, 64)
+    assert len(ops._PARKED) == 1
+    # other tensors, same shapes: while the plan is parked their memory cannot be the parked tensors' memory
+    g2 = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 300, 4, seed=54)
+    l2, a2 = dev(g2["loc"], torch.float32), dev(g2["attn"], torch.float32)
+    want2 = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g2["loc"], g2["attn"], g["grad_out"])
+    gv2, _, _ = ops.box_attn_backward(v.detach(), shapes, lsi, l2, a2, gout, 64)
+    close(gv2, want2[0], torch.float32, "grad_value (other tensors)")
+    assert len(ops._PARKED) == 1, "the parked plan is still waiting for ITS backward"
+    # in-place update of the parked locations: the version no longer matches
+    with torch.no_grad():
+        l.mul_(0.5).add_(0.25)
+    g3 = dict(g, loc=(g["loc"].astype(np.float32) * np.float32(0.5) + np.float32(0.25)).astype(np.float64))
+    want3 = oc.box_attn_backward(g3["value"], g3["shapes"], g3["lsi"], g3["loc"], g3["attn"], g3["grad_out"])
+    gv3, _, _ = ops.box_attn_backward(v.detach(), shapes, lsi, l.detach(), a.detach(), gout, 64)
+    close(gv3, want3[0], torch.float32, "grad_value (stale parked plan not taken)")
+    ops.release_workspaces()
+    assert len(ops._PARKED) == 0
+
+
 @pytest.mark.parametrize("plan_in_forward", [False, True])
 def test_functions_use_the_plan_and_match(plan_in_forward):
     """The autograd Functions with and without the forward preparing the backward's plan
