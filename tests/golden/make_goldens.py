@@ -17,7 +17,8 @@ functions are pulled out of the reference files at run time and exec'd in memory
 These are the reference's own test oracles for its CUDA op (the op has no CPU build, and
 the package itself cannot be imported here: torchvision / torch._six are missing), run in
 fp64 on CPU.  Each fixture is an .npz of inputs, expected outputs and expected gradients
-for stored upstream gradients.  Fixture ids follow SURVEY.md section 8(c): G1..G7.
+for stored upstream gradients.  Fixture ids follow SURVEY.md section 8(c): G1..G7; G8 (layers) and G9
+(modules at the model's head geometry, with gradients) were added in rounds 2 and 5.
 
 Storage notes: all expected outputs are float64.  Inputs are float64 except where a
 ``*_q8`` int8 array + ``*_scale`` is stored (value = q8 * scale, exactly representable in
@@ -510,9 +511,116 @@ def g8():
          ref_windows=dec_ref3, shapes=shapes3, lsi=lsi3, out=out3)))
 
 
+# --------------------------------------------------------------------------------------
+# G9: the modules at the MODEL's head geometry -- d = 256, 8 heads (32 channels per head), 4 levels, 2 x 2
+#     points -- with GRADIENTS: outputs and d(loss)/d(query, value, ref_windows, every parameter) for a stored
+#     upstream gradient, differentiated by torch in fp64 through the reference's own module code
+#     (box_attention.py:63-81, 196-239, 304-363).  G7 / G8 use d = 32 with 4 heads (8 channels per head), which
+#     only the generic kernels take; these shapes are the ones the window-staged / gather / binned kernel
+#     families run (encoder shape: one query per pixel, pixel-centre reference windows).
+#     Storage: inputs and parameters are int8 / 64 resp. int8 / 2048 (exact in bf16 / fp16: stored as float16),
+#     expected outputs and gradients float32 (the GPU paths compared with them are float32 / bf16).
+# --------------------------------------------------------------------------------------
+def g9():
+    ref = load_reference_modules()
+    levels = [(8, 12), (4, 6), (2, 3), (1, 2)]
+    shapes = torch.tensor(levels, dtype=torch.long)
+    lsi = lsi_of(shapes)
+    S = int(shapes.prod(1).sum())
+    d, nl, nh, B, Lq_dec = 256, 4, 8, 2, 12
+
+    def q8(gen, shape, scale):
+        return torch.randint(-127, 128, shape, generator=gen, dtype=torch.int64).double() * scale
+
+    def randomise(m, seed):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(q8(g, tuple(p.shape), 1.0 / 2048))
+
+    def pixel_windows(extra=()):
+        """encoder reference windows: one per pixel, centred on it, 4 pixels wide and high (box_transformer.py:70-116)"""
+        rows = []
+        for h, w in levels:
+            ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(w, dtype=torch.float64),
+                                    indexing="ij")
+            r = torch.stack([(xs + 0.5) / w, (ys + 0.5) / h, torch.full_like(xs, 4.0 / w),
+                             torch.full_like(ys, 4.0 / h)], -1).reshape(-1, 4)
+            rows.append(r)
+        rw = torch.cat(rows, 0)[None].repeat(B, 1, 1)
+        return rw
+
+    def run(name, m, query, value, v_mask, ratios, rw, n_out, seed):
+        g = torch.Generator().manual_seed(seed)
+        m.zero_grad(set_to_none=True)                  # (a module serves several fixtures)
+        q = query.clone().requires_grad_(True)
+        v = value.clone().requires_grad_(True)
+        r = rw.clone().requires_grad_(True)
+        outs = m(q, v, shapes, v_mask, lsi, ratios, r)
+        outs = [o for o in outs[:n_out]]
+        gouts = [q8(g, tuple(o.shape), 1.0 / 64) for o in outs]
+        sum((o * go).sum() for o, go in zip(outs, gouts)).backward()
+        arrs = {"sd." + k: t.to(torch.float16) for k, t in m.state_dict().items()}
+        for k, t in m.state_dict().items():            # (the float16 copies are exact)
+            assert torch.equal(arrs["sd." + k].double(), t.double()), k
+        arrs.update(shapes=shapes, lsi=lsi, query=query.to(torch.float16), value=value.to(torch.float16),
+                    ref_windows=rw, grad_query=q.grad.float(), grad_value=v.grad.float(),
+                    grad_ref_windows=r.grad.float())
+        if v_mask is not None:
+            arrs["v_mask"] = v_mask
+        if ratios is not None:
+            arrs["ratios"] = ratios
+        for i, (o, go) in enumerate(zip(outs, gouts)):
+            arrs["out%d" % i] = o.detach().float()
+            arrs["gout%d" % i] = go.to(torch.float16)
+        for k, p in m.named_parameters():
+            arrs["grad." + k] = p.grad.float()
+        save(name, **arrs)
+
+    def inputs(seed, Lq):
+        g = torch.Generator().manual_seed(seed)
+        return (q8(g, (B, Lq, d), 1.0 / 64), q8(g, (B, S, d), 1.0 / 64), torch.rand(B, S, generator=g) < 0.1,
+                0.7 + 0.3 * torch.rand(B, 1, 1, nl, 1, 2, generator=g), g)
+
+    # BoxAttention, encoder shape (one query per pixel, pixel-centre windows, no mask / ratios as in box_transformer.py:330)
+    m = ref.BoxAttention(d, nl, nh, kernel_size=2).double()
+    randomise(m, 100)
+    query, value, v_mask, ratios, g = inputs(101, S)
+    run("G9_module_box_enc", m, query, value, None, None, pixel_windows(), 1, 102)
+    # ... and with padded pixels + valid ratios
+    run("G9_module_box_enc_masked", m, query, value, v_mask, ratios, pixel_windows(), 1, 103)
+    # BoxAttention, decoder shape
+    query, value, v_mask, ratios, g = inputs(104, Lq_dec)
+    rw = torch.rand(B, Lq_dec, 4, generator=g)
+    rw[..., 2:4] = 0.1 + 0.4 * rw[..., 2:4]
+    run("G9_module_box_dec", m, query, value, v_mask, ratios, rw, 1, 105)
+    # Box3dAttention, encoder shape with the 8 fixed per-head angles (box3d_transformer.py:62-77)
+    m = ref.Box3dAttention(d, nl, nh, with_rotation=False, kernel_size=2).double()
+    randomise(m, 106)
+    query, value, v_mask, ratios, g = inputs(107, S)
+    ang = (torch.arange(nh, dtype=torch.float64) / nh)[None, None, :, None].expand(B, S, nh, 1)
+    rw5 = torch.cat([pixel_windows()[:, :, None, :].expand(B, S, nh, 4), ang], -1).contiguous()
+    run("G9_module_box3d_fixed_enc", m, query, value, None, None, rw5, 1, 108)
+    # Box3dAttention, decoder shape with learned rotation
+    m = ref.Box3dAttention(d, nl, nh, with_rotation=True, kernel_size=2).double()
+    randomise(m, 109)
+    query, value, v_mask, ratios, g = inputs(110, Lq_dec)
+    rw7 = torch.rand(B, Lq_dec, 7, generator=g)
+    rw7[..., 2:4] = 0.1 + 0.4 * rw7[..., 2:4]
+    run("G9_module_box3d_rot_dec", m, query, value, v_mask, ratios, rw7, 1, 111)
+    # InstanceAttention (training branch: output + mask output), decoder shape
+    m = ref.InstanceAttention(d, nl, nh, kernel_size=4).double()
+    randomise(m, 112)
+    m.inferencing = False
+    query, value, v_mask, ratios, g = inputs(113, Lq_dec)
+    rw = torch.rand(B, Lq_dec, 4, generator=g)
+    rw[..., 2:4] = 0.1 + 0.4 * rw[..., 2:4]
+    run("G9_module_inst_k4", m, query, value, v_mask, ratios, rw, 2, 114)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not found (run in the build container)"
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         if not only or fn.__name__ in only:
             fn()

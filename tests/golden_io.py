@@ -29,5 +29,6 @@ def load(name):
     return d
 
 
-BOX = [n for n in names("G") if "_box_" in n and not n.startswith("G7")]
-INST = [n for n in names("G") if "_inst_" in n and not n.startswith("G7")]
+# (operator-level fixtures; G7 / G9 are module-level, G8 layer-level)
+BOX = [n for n in names("G") if "_box_" in n and not n.startswith(("G7", "G8", "G9"))]
+INST = [n for n in names("G") if "_inst_" in n and not n.startswith(("G7", "G8", "G9"))]

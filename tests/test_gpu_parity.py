@@ -571,6 +571,121 @@ def test_fused_module_paths_match_reference_goldens(fused_grid, fused_pointwise,
     check(run(m, args(g, False, False))[0], g["out"], "Box3dAttention(fixed) out")
 
 
+# ------------------------------------------------------------------ nn.Modules at the model's head geometry (G9)
+# d = 256, 8 heads (32 channels per head), 4 levels, 2 x 2 points: the shapes the window-staged / gather / binned
+# kernels run (G7 / G8: d = 32 with 4 heads = 8 channels per head, generic kernels only).  Outputs AND gradients --
+# of query, value, reference windows and every parameter -- against what torch's autograd gives for the reference's
+# own module code in float64 (tests/golden/make_goldens.py g9), for every opt-in path, with the path that ran asserted.
+G9 = {
+    "G9_module_box_enc": ("BoxAttention", dict(kernel_size=2), 1),
+    "G9_module_box_enc_masked": ("BoxAttention", dict(kernel_size=2), 1),
+    "G9_module_box_dec": ("BoxAttention", dict(kernel_size=2), 1),
+    "G9_module_box3d_fixed_enc": ("Box3dAttention", dict(with_rotation=False, kernel_size=2), 1),
+    "G9_module_box3d_rot_dec": ("Box3dAttention", dict(with_rotation=True, kernel_size=2), 1),
+    "G9_module_inst_k4": ("InstanceAttention", dict(kernel_size=4), 2),
+}
+
+
+def _g9_run(name, dtype, fused_grid=0, fused_pointwise=False, native_bf16=False):
+    """-> (module, outputs, {name: gradient}, golden, spies)"""
+    import boxer_amd
+    from boxer_amd import ops
+    cls_name, kw, n_out = G9[name]
+    g = golden_io.load(name)
+    m = _load_module(getattr(boxer_amd, cls_name), g, d_model=256, num_level=4, num_head=8, **kw).to(dtype)
+    m.fused_grid, m.fused_pointwise, m.native_bf16 = fused_grid, fused_pointwise, native_bf16
+    if cls_name == "InstanceAttention":
+        m.inferencing = False
+
+    def t(key, grad=False):
+        if key not in g:
+            return None
+        x = dev(g[key])
+        x = x.to(dtype) if x.is_floating_point() else x
+        return x.requires_grad_() if grad else x
+    query, value, rw = t("query", True), t("value", True), t("ref_windows", True)
+    spies = {"plans": [], "from_boxes": []}
+    orig_train, orig_boxes = ops._forward_train, ops.box_attn_forward_from_boxes
+
+    def spy_train(*a, **k):
+        spies["plans"].append(orig_train(*a, **k))
+        return spies["plans"][-1]
+
+    def spy_boxes(*a, **k):
+        spies["from_boxes"].append(orig_boxes(*a, **k))
+        return spies["from_boxes"][-1]
+    ops._forward_train, ops.box_attn_forward_from_boxes = spy_train, spy_boxes
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native_bf16):
+            outs = m(query, value, dev(g["shapes"]), t("v_mask"), dev(g["lsi"]), t("ratios"), rw)[:n_out]
+        loss = sum((o.double() * dev(g["gout%d" % i]).double()).sum() for i, o in enumerate(outs))
+        loss.backward()
+    finally:
+        ops._forward_train, ops.box_attn_forward_from_boxes = orig_train, orig_boxes
+    grads = {"query": query.grad, "value": value.grad, "ref_windows": rw.grad}
+    grads.update({"param." + k: p.grad for k, p in m.named_parameters()})
+    return m, outs, grads, g, spies
+
+
+def _g9_check(name, outs, grads, g, tol, what, rms_only=()):
+    """Every output and gradient: max |got - want| / max(1, max |want|) <= tol; for the tensors named in `rms_only`
+    the relative root-mean-square error instead (bf16 autocast: the box offsets are bf16 numbers, a few sample
+    points per image land on the other side of a bilinear cell edge than in the float64 run, and the gradients
+    that flow through the LOCATIONS -- reference windows, box projection, query -- jump there; the reference under
+    autocast has the same sensitivity)."""
+    def errs(got, want):
+        got = got.detach().double().cpu().numpy()
+        want = np.asarray(want, dtype=np.float64).reshape(got.shape)
+        return (float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())),
+                float(np.sqrt(((got - want) ** 2).mean()) / max(1e-30, np.sqrt((want ** 2).mean()))))
+    worst = {}
+    for i, o in enumerate(outs):
+        worst["out%d" % i] = errs(o, g["out%d" % i])[0]
+    for k, v in grads.items():
+        key = "grad_" + k if not k.startswith("param.") else "grad." + k[6:]
+        assert v is not None, "%s: no gradient reached %s" % (name, k)
+        e_max, e_rms = errs(v, g[key])
+        worst[k] = e_rms / 2 if any(r in k for r in rms_only) else e_max       # (rms criterion: 2 tol)
+    bad = {k: v for k, v in worst.items() if not v <= tol}
+    assert not bad, "%s %s: errors above %.0e: %s" % (name, what, tol, bad)
+
+
+@pytest.mark.parametrize("name", sorted(G9))
+def test_g9_modules_float64(name):
+    """float64 (the generic kernels): the module glue -- projections, box decoding, softmax, masks, rotation -- and
+    every gradient through it agree with the reference's module code to float32 storage precision."""
+    _, outs, grads, g, _ = _g9_run(name, torch.float64)
+    _g9_check(name, outs, grads, g, 2e-6, "float64")
+
+
+@pytest.mark.parametrize("native_bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("fused_pointwise", [False, True], ids=["torch_pointwise", "fused_pointwise"])
+@pytest.mark.parametrize("fused_grid", [0, 1, 2])
+@pytest.mark.parametrize("name", sorted(G9))
+def test_g9_modules_fast_paths(name, fused_grid, fused_pointwise, native_bf16):
+    """float32 / bf16 storage on the fast kernel families, every opt-in path (fused_grid 1: grid kernels, 2: boxes
+    straight into the sampling kernels; fused_pointwise; native bf16) -- and it is ASSERTED that the fast path ran:
+    the training forward built the binned backward's plan (32 channels per head: eligible), fused_grid = 2 took the
+    from-boxes kernels where they exist (box attention, float32 / bf16), and the bf16 encoder shapes ran the
+    window-staged forward (it is the only kernel that feeds the locality counters of the state buffer)."""
+    from boxer_amd import ops
+    ops.release_workspaces()
+    m, outs, grads, g, spies = _g9_run(name, torch.float32, fused_grid, fused_pointwise, native_bf16)
+    _g9_check(name, outs, grads, g, 4e-2 if native_bf16 else 2e-4,
+              "fused_grid=%s pointwise=%s bf16=%s" % (fused_grid, fused_pointwise, native_bf16),
+              rms_only=("ref_windows", "linear_box", "query") if native_bf16 else ())
+    is_box = "inst" not in name
+    if fused_grid == 2 and is_box:
+        assert spies["from_boxes"] and all(r is not None for r in spies["from_boxes"]), \
+            "fused_grid = 2 fell back to the unfused kernels"
+    else:
+        assert spies["plans"] and all(p is not None for p in spies["plans"]), "no plan: not on the binned fast path"
+    if native_bf16 and name.endswith(("_enc", "_enc_masked")) and fused_grid != 2:
+        torch.cuda.synchronize()
+        counted = sum(int(st[:1024].view(torch.int64).sum().item()) for st in ops._STATE.values())
+        assert counted > 0, "the window-staged forward did not run (no locality counts)"
+
+
 # ------------------------------------------------------------------ box -> grid (opt-in)
 def _torch_grid(ref, off, kidx, vr, angle_mode):
     """The reference modules' _where_to_attend after the offset projection
