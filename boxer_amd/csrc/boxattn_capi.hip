@@ -867,7 +867,10 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
     const bool allow_dense = !(hints & BOXATTN_HINT_NOT_LOCAL);
     // the locality counters of the window-staged forward, then the riders' tickets
     const size_t tbytes = (size_t)std::max(0, d.B) * (size_t)std::max(0, d.H) * kRideTickets * sizeof(int);
-    const bool have_state = state && state_bytes >= kStatBytes + tbytes && aligned(state, 8);
+    // (a state buffer that is too small or misaligned is an error, not "no state": the caller would silently lose the
+    // locality counters and pay a zero-fill launch in front of every forward)
+    if (state && (!aligned(state, 8) || state_bytes < kStatBytes + tbytes)) return (int)hipErrorInvalidValue;
+    const bool have_state = state != nullptr;
     unsigned long long *stats = have_state ? (unsigned long long *)state : nullptr;
     BinPlan plan;
     bool ok = (g_variant == 0 || g_variant == 3) && plan_buf && d.valid() &&

@@ -213,8 +213,10 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * slot, the work-item list; 1.4 MB at BoxeR-R50 encoder shapes).  It must stay untouched until the
  * matching *_bwd_ws_* call.  *plan_built is 1 if a plan was built, 0 if the call was just a plain
  * forward (shape not eligible / buffer too small / NULL).
- * state / state_bytes: NULL / 0, or a device buffer of boxattn_state_bytes(B, H) bytes (4-byte aligned) that
+ * state / state_bytes: NULL / 0, or a device buffer of at least boxattn_state_bytes(B, H) bytes, 8-byte aligned (its
+ * first KiB are 64-bit counters), that
  * the caller ZEROED ONCE and keeps for the calls it issues on THIS stream: the riders' hand-off tickets.
+ * A non-NULL state that is misaligned or too small is an error (hipErrorInvalidValue), not "no state".
  * Every call leaves it zero again, and calls on one stream never overlap, so it is never cleared again.
  * Without it the tickets live in `plan` and a zero-fill launch (~5 us) precedes the forward kernel.
  * The FIRST 1 KiB of the state buffer holds 64 pairs of uint64 counters (the tickets follow; one buffer serves

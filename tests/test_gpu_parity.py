@@ -1038,6 +1038,39 @@ def test_training_forward_plan(dtype):
     close(gv3, want3[0], dtype, "grad_value (plan with stale weights ignored)")
 
 
+def test_training_forward_refuses_a_bad_state_buffer():
+    """include/boxattn.h: a non-NULL state buffer must be 8-byte aligned and boxattn_state_bytes(B, H) bytes long -- a
+    buffer that is not is an error (hipErrorInvalidValue = 1), not silently "no state" (which would cost the locality
+    counters and a zero-fill launch per forward without anybody noticing)."""
+    import ctypes
+    from boxer_amd import _lib
+    lib = _lib.load()
+    g = _seeded([(20, 30), (10, 15)], 1, 8, 32, 50, 4, seed=59)
+    value, loc, attn = dev(g["value"], torch.float32), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
+    shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
+    B, S, H, C = value.shape
+    L, Lq, P = shapes.size(0), loc.size(1), loc.size(4)
+    out = torch.empty(B, Lq, H * C, device="cuda")
+    sh, ls = np.ascontiguousarray(g["shapes"]), np.ascontiguousarray(g["lsi"])
+    nplan = int(lib.boxattn_plan_bytes(0, B, S, H, C, L, Lq, P, sh.ctypes.data, ls.ctypes.data))
+    plan = torch.empty(nplan, dtype=torch.uint8, device="cuda")
+    nstate = int(lib.boxattn_state_bytes(B, H))
+    state = torch.zeros(nstate + 16, dtype=torch.uint8, device="cuda")
+    built = ctypes.c_int(0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(state_ptr, state_bytes):
+        return lib.boxattn_fwd_train_f32(value.data_ptr(), shapes.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+                                         attn.data_ptr(), B, S, H, C, L, Lq, P, out.data_ptr(), sh.ctypes.data,
+                                         ls.ctypes.data, plan.data_ptr(), plan.numel(), state_ptr, state_bytes, 0,
+                                         ctypes.addressof(built), stream)
+    assert call(state.data_ptr(), nstate) == 0 and built.value == 1
+    assert call(state.data_ptr() + 4, nstate) == 1, "misaligned state"
+    assert call(state.data_ptr(), nstate - 8) == 1, "undersized state"
+    assert call(0, 0) == 0 and built.value == 1, "no state at all is fine (tickets in the plan buffer)"
+    torch.cuda.synchronize()
+
+
 def _ref_style_function(mod):
     """An autograd Function in the reference's own shape (box_attention_func.py:10-64): forward saves the five
     tensors and calls ``box_attn_forward``; backward calls ``box_attn_backward`` with nothing but them."""

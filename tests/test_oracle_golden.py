@@ -142,3 +142,24 @@ def test_oracle_window_test_at_exactly_minus_one():
     loc[..., 0] = 1 + 0.5 / 4                                        # w_im = W exactly
     gv, gl, ga = oc.box_attn_backward(value, shapes, lsi, loc, attn, np.ones_like(out))
     assert not gv.any() and not gl.any() and not ga.any()
+
+
+def test_g9_fixtures_are_complete():
+    """G9 (tests/golden/make_goldens.py g9): the reference's modules at d = 256 / 8 heads / 4 levels with gradients.  The
+    GPU tests compare every opt-in path of boxer_amd.modules with them; here only that each fixture holds what those
+    tests read: a state dict, inputs, an upstream gradient per output, and a gradient for every input and parameter."""
+    import golden_io
+    names = golden_io.names("G9_")
+    assert len(names) == 6, names
+    for name in names:
+        g = golden_io.load(name)
+        params = [k[3:] for k in g if k.startswith("sd.") and k[3:] != "kernel_indices"]
+        assert params and all("grad." + k in g and g["grad." + k].shape == g["sd." + k].shape for k in params), name
+        for k in ("query", "value", "ref_windows"):
+            assert g["grad_" + k].shape == g[k].shape, (name, k)
+        n_out = 2 if "inst" in name else 1
+        assert all(g["out%d" % i].shape == g["gout%d" % i].shape for i in range(n_out)), name
+        assert g["value"].shape[-1] == 256 and g["shapes"].shape == (4, 2)
+        for k in g:                                   # finite numbers only
+            if g[k].dtype.kind == "f":
+                assert np.isfinite(g[k]).all(), (name, k)

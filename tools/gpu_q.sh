@@ -1,4 +1,24 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -k "g9 or golden" 2>&1 | grep -E "Error|assert|error|passed|failed" | head -30
+timeout 1200 python -m pytest tests -m gpu -q -x -k "golden or vs_oracle or algorithms or run_to_run or single_terms or nonfinite or fullsize or soak or records_per_item or clustered" 2>&1 | tail -5
+run() {  # dtype, extra args...
+  local dt=$1; shift
+  timeout 300 python bench.py --steps 300 --warmup 20 --dtype $dt --no-cpu-baseline --rotate 0 "$@" 2>&1 | tail -1 | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.readline()); k=d['roofline'].get('kernels',{})
+    print('%-34s %s %.4f Gpts/s %.4f ms | '%(' '.join(sys.argv[1:]), d['dtype'], d['value'], d['ms_per_step']) + ' '.join('%s=%.1f'%(n,v['avg_ms']*1e3) for n,v in k.items()))
+except Exception as e: print('bench failed', sys.argv[1:], e)
+" "$@"
+}
+run bf16
+run bf16 --opt 21=1
+run bf16
+run bf16 --opt 21=1
+run bf16 --opt 15=1
+run bf16 --opt 15=1 --opt 21=1
+run bf16 --workload C2p
+run bf16 --workload C2p --opt 21=1
+run bf16 --inputs test
+run bf16 --inputs test --opt 21=1
