@@ -44,13 +44,14 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
                               // of 8 workgroups (s = 0: all in front); | v << 8: 64 v bin workgroups (riders) in all;
                               // 0: defaults
-       kNumOpts = 21 };
+       kOptDenseF32 = 21,     // window-staged encoder kernels for FLOAT32 box attention: 0 default (on), 1 off (gather kernels)
+       kNumOpts = 22 };
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 inline bool opt_live(int k)
 {
     return k == kOptBinChunk || k == kOptDense || k == kOptDenseJit || k == kOptDenseRef || k == kOptRiders ||
-           k == kOptDenseFwd || k == kOptAccF32 || k == kOptRideShift;
+           k == kOptDenseFwd || k == kOptAccF32 || k == kOptRideShift || k == kOptDenseF32;
 }
 #ifndef BOXATTN_RIDE_SHIFT_COUNT
 #define BOXATTN_RIDE_SHIFT_COUNT 0     // count riders: all in front of the forward kernel's grid (measured: interleaving
@@ -277,7 +278,7 @@ inline BinRide place_riders(const BinRide *ride_in, unsigned own_blocks, unsigne
 }
 
 // ------------------------------------------------------------------------------ forward
-inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p);
+inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p, int elem);
 
 // count_ride: the backward's count pass + scans to run as rider workgroups of the forward kernel (training
 // forward); *ride_taken says whether the kernel that was launched carried them
@@ -309,10 +310,21 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             if constexpr (!INST && std::is_same<ST, bf16_t>::value) {     // encoder case: window-staged matrix-core forward
                 DensePlan dp;
                 if (allow_dense && opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
-                    aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp)) {
+                    aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp, 2)) {
                     ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
                     launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)),
                                      count_ride ? *count_ride : BinRide{}, stats, st);
+                    if (count_ride && ride_taken) *ride_taken = true;
+                    return finish();
+                }
+            }
+            if constexpr (!INST && std::is_same<ST, float>::value) {      // encoder case, float32: window-staged VALU forward
+                DensePlan dp;
+                if (allow_dense && opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
+                    aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp, 4)) {
+                    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
+                    launch_fwd_dense_f32(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(float)),
+                                         count_ride ? *count_ride : BinRide{}, stats, st);
                     if (count_ride && ride_taken) *ride_taken = true;
                     return finish();
                 }
@@ -629,6 +641,14 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
             return;
         }
     }
+    if constexpr (std::is_same<ST, float>::value && !INST) {
+        if (!gs && dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
+            launch_pointgrad_dense_f32(value, loc, w_sp, grad_out, *dp, grad_loc, grad_sp,
+                                       (unsigned)(d.n_value() * sizeof(float)), st, fill_ride ? *fill_ride : BinRide{});
+            if (fill_ride && ride_taken) *ride_taken = true;
+            return;
+        }
+    }
     const size_t n_qh = d.n_qh();
     const size_t vbytes = d.n_value() * sizeof(ST);
     GatherIdx ix{};
@@ -837,8 +857,8 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     char *sbuf = plan_ready ? ws : ws + pl.total;
     int rc = 0;
     DensePlan dense;
-    const DensePlan *dp = kBf16 && !INST && !(hints & BOXATTN_HINT_NOT_LOCAL) &&
-                                  make_dense_plan(d, shapes_host, lsi_host, dense) ? &dense : nullptr;
+    const DensePlan *dp = !std::is_same<ST, double>::value && !INST && !(hints & BOXATTN_HINT_NOT_LOCAL) &&
+                                  make_dense_plan(d, shapes_host, lsi_host, dense, (int)sizeof(ST)) ? &dense : nullptr;
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \

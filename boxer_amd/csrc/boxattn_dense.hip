@@ -6,6 +6,7 @@
 #include "boxattn_dense.h"
 #include "boxattn_binned_tr.h"
 #include "boxattn_dense_fwd.h"
+#include "boxattn_dense_f32.h"
 
 namespace boxattn {
 
@@ -48,6 +49,39 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
         BOXATTN_DENSE_FWD(1) BOXATTN_DENSE_FWD(2) BOXATTN_DENSE_FWD(3) BOXATTN_DENSE_FWD(4)
     }
 #undef BOXATTN_DENSE_FWD
+}
+
+void launch_pointgrad_dense_f32(const float *value, const float *loc, const float *attn, const float *grad_out,
+                                const DensePlan &dp, float *grad_loc, float *grad_attn, unsigned value_bytes,
+                                hipStream_t st, const BinRide &ride_in)
+{
+    unsigned total = 0;
+    const BinRide ride = place_riders(ride_in, dense_blocks(dp), &total);
+#define BOXATTN_DENSE_PG32(LV_)                                                                         \
+    case LV_:                                                                                           \
+        hipLaunchKernelGGL((pointgrad_dense_f32_kernel<LV_>), dim3(total), dim3(256), 0, st, value, loc, attn, \
+                           grad_out, grad_loc, grad_attn, dp, value_bytes, ride);                      \
+        break;
+    switch (dp.L) {
+        BOXATTN_DENSE_PG32(1) BOXATTN_DENSE_PG32(2) BOXATTN_DENSE_PG32(3) BOXATTN_DENSE_PG32(4)
+    }
+#undef BOXATTN_DENSE_PG32
+}
+
+void launch_fwd_dense_f32(const float *value, const float *loc, const float *attn, float *out, const DensePlan &dp,
+                          unsigned value_bytes, const BinRide &ride_in, unsigned long long *stats, hipStream_t st)
+{
+    unsigned total = 0;
+    const BinRide ride = place_riders(ride_in, dense_blocks(dp), &total);
+#define BOXATTN_DENSE_FWD32(LV_)                                                                     \
+    case LV_:                                                                                        \
+        hipLaunchKernelGGL((fwd_dense_f32_kernel<LV_>), dim3(total), dim3(256), 0, st, value, loc, attn, out, \
+                           dp, value_bytes, ride, stats);                                            \
+        break;
+    switch (dp.L) {
+        BOXATTN_DENSE_FWD32(1) BOXATTN_DENSE_FWD32(2) BOXATTN_DENSE_FWD32(3) BOXATTN_DENSE_FWD32(4)
+    }
+#undef BOXATTN_DENSE_FWD32
 }
 
 void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S,

@@ -84,6 +84,16 @@ void launch_fwd_dense(const uint16_t *value, const float *loc, const float *attn
                       const DensePlan &dp, unsigned value_bytes, const BinRide &ride,
                       unsigned long long *stats, hipStream_t st);
 
+// float32 storage (boxattn_dense_f32.h): the plan's window geometry in 32-byte units (make_dense_plan with 4-byte elements)
+void launch_pointgrad_dense_f32(const float *value, const float *loc, const float *attn, const float *grad_out,
+                                const DensePlan &dp, float *grad_loc, float *grad_attn, unsigned value_bytes,
+                                hipStream_t st, const BinRide &ride);
+void launch_fwd_dense_f32(const float *value, const float *loc, const float *attn, float *out, const DensePlan &dp,
+                          unsigned value_bytes, const BinRide &ride, unsigned long long *stats, hipStream_t st);
+#ifndef BOXATTN_DENSE_F32_LDS
+#define BOXATTN_DENSE_F32_LDS 53248
+#endif
+
 // The matrix-core accumulate of bf16 box attention (boxattn_binned_tr.h; lives in this translation unit
 // because it mixes float32 VALU work with MFMAs, see boxattn_dense.hip).  C = 16, 32 or 64 channels per
 // head, grad_out below 2 GB (32-bit row offsets, and an out-of-range offset for idle lanes).

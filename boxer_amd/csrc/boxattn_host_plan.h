@@ -213,12 +213,17 @@ inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
 
 // ------------------------------------------------- window-staged encoder kernels (boxattn_dense.h)
 // Encoder case: one query per pixel of packed levels, bf16 storage, C = 32, 2x2 points, <= 4 levels.
-inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p)
+// elem: bytes per stored element -- 2: bf16 storage (64-byte pixels, geometry in 16-byte units, boxattn_dense.h),
+// 4: float32 storage (128-byte pixels, 32-byte units, boxattn_dense_f32.h)
+inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p, int elem)
 {
     if (!sh || !ls || !d.valid() || opt(kOptDense) == 1 || g_variant == 1 || g_variant == 2) return false;
+    if (elem == 4 && opt(kOptDenseF32) == 1) return false;
     if (d.Lq != d.S || d.C != 32 || d.P != 4 || d.L > kDenseMaxLevels || d.B < 1 || d.S < 1) return false;
     if ((size_t)d.B * d.Lq * d.H * d.L * d.P >= (1ull << 31)) return false;       // 32-bit point ids
-    if (d.n_value() * sizeof(bf16_t) >= kOobOffset) return false;
+    if (d.n_value() * (size_t)elem >= kOobOffset) return false;
+    const int unit = 8 * elem;                                  // bytes per unit of a window's pitch / offset
+    const int budget = elem == 2 ? kDenseZeroOff : BOXATTN_DENSE_F32_LDS - 128;      // (minus the forwards' row of zeros)
     p = DensePlan{};
     p.dbg = g_dense_dbg.load();
     p.L = d.L; p.B = d.B; p.Lq = d.Lq; p.S = d.S; p.H = d.H;
@@ -262,8 +267,8 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
             w.ax = (int)std::lround(kDenseTile * rx * 65536.0f); w.bx = (int)std::floor((0.5f * rx - 0.5f - mx) * 65536.0f);
             w.ay = (int)std::lround(kDenseTile * ry * 65536.0f); w.by = (int)std::floor((0.5f * ry - 0.5f - my) * 65536.0f);
             if (rx > 8.0f || ry > 8.0f) { w.ax = w.ay = 0; }      // (not staged anyway; keeps tx * ax inside 31 bits)
-            const int need = rows * dense_win_pitch16(cols);       // in 16-byte units
-            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && 16 * (used + need) <= kDenseZeroOff;
+            const int need = rows * dense_win_pitch16(cols);       // in units (a pixel = 4 units, a row = its pixels + 1)
+            const bool fits = cols <= kDenseWinMax && rows <= kDenseWinMax && unit * (used + need) <= budget;
             w.geo = dense_win_pack(fits ? rows : 0, fits ? cols : 0, used);
             if (fits) used += need;
         }

@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -x -k "golden or vs_oracle or algorithms or run_to_run or single_terms or nonfinite or fullsize or soak or records_per_item or clustered" 2>&1 | tail -5
+timeout 1200 python -m pytest tests -m gpu -q -x -k "fullsize or golden or vs_oracle or dense or sweep or linearity or nonfinite or outside" 2>&1 | tail -4
 run() {  # dtype, extra args...
   local dt=$1; shift
   timeout 300 python bench.py --steps 300 --warmup 20 --dtype $dt --no-cpu-baseline --rotate 0 "$@" 2>&1 | tail -1 | python -c "
@@ -12,13 +12,9 @@ try:
 except Exception as e: print('bench failed', sys.argv[1:], e)
 " "$@"
 }
-run bf16
-run bf16 --opt 21=1
-run bf16
-run bf16 --opt 21=1
-run bf16 --opt 15=1
-run bf16 --opt 15=1 --opt 21=1
-run bf16 --workload C2p
-run bf16 --workload C2p --opt 21=1
-run bf16 --inputs test
-run bf16 --inputs test --opt 21=1
+run fp32
+run fp32 --opt 15=1
+run fp32 --opt 19=2
+run fp32 --workload C2p
+run fp32 --workload C5p
+run fp32 --workload C5p --opt 21=1
