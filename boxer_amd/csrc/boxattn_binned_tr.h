@@ -299,6 +299,240 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     }
 }
 
+// FLOAT32 storage on the bf16 matrix cores, exactly: every float32 number is the sum of three bf16 numbers
+// (x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2: 8 + 8 + 8 significand bits, each
+// difference exact), bf16 x bf16 products are exact in float32, and the matrix cores accumulate in float32.  With the
+// upstream rows g and the weights w both split, w g = sum_{i,j} w_i g_j; the six products with i + j <= 4 carry
+// everything above 2^-24 |w g| -- what a float32 fused multiply-add keeps of the product -- and are summed into the
+// float32 accumulators like the terms of the reference's float32 sum (in another, still unspecified, order).  Against
+// the VALU list walk of binned_accumulate_kernel (float32 box attention, C = 32: 102 us at C2) a round of 64 records is
+// 24 v_mfma_f32_32x32x16_bf16 (768 matrix-pipe cycles; the float32 MFMA flavour below needs 2 048) + the splitting of
+// the 64 gathered rows on the VALU (the price of float32 storage: ~180 instructions a round).
+//   rows:    gathered 128-byte rows -> registers -> split -> two bf16 planes G1, G2 in LDS (G3 follows into G1's place
+//            once G1's operands have been read) -> ds_read_b64_tr_b16 -> the three operand sets stay in registers;
+//   weights: A^T[pixel][record] as in the bf16 kernel, written three times (w1, w2, w3 over the same slots);
+//   products: w1 (g1, g2, g3), w2 (g1, g2), w3 g1.
+// Wide records {id, x, y, weight}; the next round's rows are requested as soon as this round's have been split (one
+// register buffer).
+template <int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void binned_accumulate_split_kernel(
+    const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
+    const int4 *__restrict__ items, const int *__restrict__ n_items,
+    const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc,
+    ZeroRole zr)
+{
+    static_assert(C == 32, "channels per head");
+    constexpr int BW = 8, PB = 32, R = 64;
+    constexpr int ROWB = C * 4;                    // bytes of one upstream-gradient row
+    constexpr int LPR = ROWB / 16;                 // lanes that fetch one row, 16 B each (8)
+    constexpr int RPP = 64 / LPR;                  // rows fetched per pass (8)
+    constexpr int NPASS = R / RPP;                 // 8
+    constexpr int GPL = R * 64;                    // bytes of one bf16 plane: [record][32 channels]
+    constexpr int AS = 72, ASB = AS * 2;
+    constexpr int kDump = PB * ASB;
+    constexpr int kBig = 1 << 20;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned short gs[2 * GPL / 2];
+    __shared__ __attribute__((aligned(16))) unsigned short at[(PB + 1) * AS];
+    __shared__ int last_flag;
+
+    const int n_slices = plan.n_slices, workers = (int)gridDim.x - plan.zero_workers;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = bid % 8, kq = bid / 8;
+    const int per_xcd = (n_slices + 7) / 8;
+    const int s = slice_on_xcd(xcd, kq % per_xcd, per_xcd);
+    const int worker = kq / per_xcd - plan.zero_workers;
+    if (s >= n_slices || worker >= workers) return;
+    const int b = s / H, h = s % H;
+    const int lane = threadIdx.x;
+    if (worker < 0) {
+        zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        return;
+    }
+    const int col = lane & 31, kb = lane >> 5;
+    const int n_it = n_items[2 * s];
+    for (int i = lane; i < (PB + 1) * AS / 2; i += 64) reinterpret_cast<unsigned int *>(at)[i] = 0u;
+    wave_lds_sync();
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out), 0, grad_out_bytes, 0x00020000);
+    const unsigned slice_off = (unsigned)((b * Lq) * H + h) * (unsigned)ROWB;
+    const unsigned q_stride = (unsigned)(H * ROWB);
+    const int piece = lane % LPR, jrow = lane / LPR;
+    // staging: record jrow (+ 8 per pass), channels 4 piece .. 4 piece + 3 as 4 bf16 = 8 bytes of its plane row
+    const unsigned stage_off = (unsigned)(jrow * 64 + piece * 8);
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const unsigned tr_off = (unsigned)((8 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2);
+    unsigned a_off = (unsigned)(col * ASB + 16 * kb);
+    asm volatile("" : "+v"(a_off));
+
+    const int4 *my_items = items + (size_t)s * plan.item_cap;
+    int4 item_n = my_items[min(worker, plan.item_cap - 1)];
+    for (int it = worker; it < n_it; it += workers) {
+        const int4 item = item_n;
+        item_n = my_items[min(it + workers, plan.item_cap - 1)];
+        const BlockGeo bg = unpack_block_geo((unsigned)item.x);
+        int lvH = plan.lv[0].H, lvW = plan.lv[0].W, lv_start = plan.lv[0].start;
+#pragma unroll
+        for (int k = 1; k < kMaxBinLevels; ++k)
+            if (k == bg.level) { lvH = plan.lv[k].H; lvW = plan.lv[k].W; lv_start = plan.lv[k].start; }
+        const int oy = bg.oy, ox = bg.ox, bh = bg.bh, bw = bg.bw;
+        const float Hf = (float)lvH, Wf = (float)lvW;
+        const int4 *rec = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
+        tr_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        constexpr unsigned kNoRow = 0x80000000u;       // outside the buffer: zeros (idle lanes of a last round)
+        auto fetch_rec = [&](int rr) -> int4 {
+            if (rr + lane >= item.z) return make_int4(-1, 0, 0, 0);
+            return rec[rr + lane];
+        };
+        u32x4 rows[NPASS];
+        auto fetch_rows = [&](const int4 &r) {
+            const unsigned off = r.x < 0 ? kNoRow : __umul24((unsigned)r.x >> plan.lp_bits, q_stride) + slice_off;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const unsigned oj = (unsigned)__shfl((int)off, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
+                rows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, oj, 0, 0);
+            }
+        };
+        // x -> its leading bf16 term (packed pairs) and the exact remainder
+        auto split2 = [](float &x0, float &x1) -> unsigned {
+            const unsigned pk = pack_bf16x2(x0, x1);
+            x0 -= __uint_as_float(pk << 16);
+            x1 -= __uint_as_float(pk & 0xffff0000u);
+            return pk;
+        };
+        int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
+        fetch_rows(rec_c);
+        for (int rr = item.y; rr < item.z; rr += R) {
+            const bool more = rr + R < item.z;         // wave-uniform
+            int4 rec_n3 = make_int4(-1, 0, 0, 0);
+            if (rr + 3 * R < item.z) rec_n3 = fetch_rec(rr + 3 * R);
+            // ---- the rows of this round: split into three bf16 terms; planes G1, G2 to LDS, G3 kept packed
+            uint2 g3pk[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                float x0 = __uint_as_float(rows[ps].x), x1 = __uint_as_float(rows[ps].y);
+                float x2 = __uint_as_float(rows[ps].z), x3 = __uint_as_float(rows[ps].w);
+                uint2 t1, t2;
+                t1.x = split2(x0, x1); t1.y = split2(x2, x3);
+                t2.x = split2(x0, x1); t2.y = split2(x2, x3);
+                g3pk[ps] = uint2{pack_bf16x2(x0, x1), pack_bf16x2(x2, x3)};            // (exact: <= 8 bits are left)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(gs) + stage_off + ps * RPP * 64) = t1;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(gs) + GPL + stage_off + ps * RPP * 64) = t2;
+            }
+            if (more) fetch_rows(rec_n);               // (the row registers are free again: the next round's rows)
+            // ---- lane = record: its <= 4 weights, three bf16 terms each
+            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
+            float h_im, w_im;
+            {
+#pragma clang fp contract(off)                   // two roundings, as in locate()
+                h_im = y * Hf - 0.5f;
+                w_im = x * Wf - 0.5f;
+            }
+            const float yf = floorf(h_im), xf = floorf(w_im);
+            const float lh = h_im - yf, lw = w_im - xf, hh = 1.f - lh, hw = 1.f - lw;
+            // (the reference's products: (hh hw) a etc. -- in that order)
+            float w0 = hh * hw * a, w1 = hh * lw * a, w2 = lh * hw * a, w3 = lh * lw * a;
+            const unsigned t1_01 = split2(w0, w1), t1_23 = split2(w2, w3);
+            const unsigned t2_01 = split2(w0, w1), t2_23 = split2(w2, w3);
+            const unsigned t3_01 = pack_bf16x2(w0, w1), t3_23 = pack_bf16x2(w2, w3);
+            const int py = rec_c.x >= 0 ? (int)yf - oy : -2, px = (int)xf - ox;
+            const int r0 = (unsigned)py < (unsigned)bh ? __mul24(py, BW * ASB) : kBig;
+            const int r1 = (unsigned)(py + 1) < (unsigned)bh ? __mul24(py, BW * ASB) + BW * ASB : kBig;
+            const int c0 = (unsigned)px < (unsigned)bw ? __mul24(px, ASB) + 2 * lane : kBig;
+            const int c1 = (unsigned)(px + 1) < (unsigned)bw ? __mul24(px, ASB) + 2 * lane + ASB : kBig;
+            const int dump = kDump + 2 * lane;
+            const int slot[4] = {min(r0 + c0, dump), min(r0 + c1, dump), min(r1 + c0, dump), min(r1 + c1, dump)};
+            auto put4 = [&](unsigned p01, unsigned p23) {
+                *reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(at) + slot[0]) = (unsigned short)(p01 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(at) + slot[1]) = (unsigned short)(p01 >> 16);
+                *reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(at) + slot[2]) = (unsigned short)(p23 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(at) + slot[3]) = (unsigned short)(p23 >> 16);
+            };
+            put4(t1_01, t1_23);
+            wave_lds_sync();
+            // ---- operands: G1, G2 now; G3 goes into G1's plane once G1 has been read
+            tr_bf16x8 g1[R / 16], g2[R / 16], g3[R / 16];
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const uint2 a0 = lds_read_tr16(gs, tr_off + t * 1024), a1 = lds_read_tr16(gs, tr_off + t * 1024 + 256);
+                g1[t] = __builtin_bit_cast(tr_bf16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+                const uint2 b0 = lds_read_tr16(gs, GPL + tr_off + t * 1024), b1 = lds_read_tr16(gs, GPL + tr_off + t * 1024 + 256);
+                g2[t] = __builtin_bit_cast(tr_bf16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(gs) + stage_off + ps * RPP * 64) = g3pk[ps];
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const uint2 a0 = lds_read_tr16(gs, tr_off + t * 1024), a1 = lds_read_tr16(gs, tr_off + t * 1024 + 256);
+                g3[t] = __builtin_bit_cast(tr_bf16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+            }
+            // ---- products, the small ones first: w1 g3, w1 g2, w1 g1; w2 g2, w2 g1; w3 g1
+            auto weights = [&](int t) -> tr_bf16x8 {
+                return __builtin_bit_cast(
+                    tr_bf16x8, *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(at) + a_off + 32 * t));
+            };
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const tr_bf16x8 pw = weights(t);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g3[t], pw, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[t], pw, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[t], pw, acc, 0, 0, 0);
+            }
+            wave_lds_sync();
+            put4(t2_01, t2_23);
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t) {
+                const tr_bf16x8 pw = weights(t);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[t], pw, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[t], pw, acc, 0, 0, 0);
+            }
+            wave_lds_sync();
+            put4(t3_01, t3_23);
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < R / 16; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[t], weights(t), acc, 0, 0, 0);
+            wave_lds_sync();
+            put4(0u, 0u);
+            rec_c = rec_n; rec_n = rec_n2; rec_n2 = rec_n3;
+            wave_lds_sync();
+        }
+        // ---- store.  Lane = pixel `col`; its registers hold channels 8 g + 4 kb + 0..3.
+        if (item.w < 0) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int py = (ln & 31) / BW, px = (ln & 31) % BW, kbs = ln >> 5;
+            const bool live = py < bh && px < bw;
+            float *dst = grad_value + (((size_t)b * S + lv_start + (size_t)(oy + py) * lvW + (ox + px)) * H + h) * C;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                if (live)
+                    *reinterpret_cast<float4 *>(dst + 8 * g4 + 4 * kbs) =
+                        make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+        } else {
+            const bool publish = cc.tickets != nullptr;
+            const __amdgpu_buffer_rsrc_t tile =
+                partial_tile(partials, s, plan.pslot_cap, item.w & ((1 << kItemSlotBits) - 1), C);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned lane_off = (unsigned)(((ln & 31) * C + 4 * (ln >> 5)) * 4);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                partial_store(tile, lane_off + (unsigned)(32 * g4),
+                              make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]), publish);
+            if (publish) chunk_finish<float, C>(cc, partials, lv_start, lvW, S, H, grad_value, s, item.w, lane, &last_flag);
+        }
+    }
+}
+
 // float32 storage, 32 channels per head: the same product on v_mfma_f32_32x32x2_f32 -- float32 operands, float32
 // products and accumulation: no splitting, no rounding beyond what any float32 summation order has (the VALU
 // list walk of binned_accumulate_kernel is float32 too, in another order).  An operand of that instruction is ONE

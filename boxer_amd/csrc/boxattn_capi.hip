@@ -40,7 +40,8 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
                               // 0 default (on; the combine inside the accumulate launch only for small problems), 1 off
                               // (launches of their own), 2 on except the combine (its own launch), 3 on, combine inside
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
-       kOptAccF32 = 19,       // float32 box attention, C = 32: accumulate on v_mfma_f32_32x32x2_f32: 0 / 1 off (VALU list walk), 2 on
+       kOptAccF32 = 19,       // float32 box attention, C = 32, accumulate: 0 default (bf16 matrix cores on exact three-term
+                              // splits), 1 VALU list walk (4-byte records), 2 v_mfma_f32_32x32x2_f32
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
                               // of 8 workgroups (s = 0: all in front); | v << 8: 64 v bin workgroups (riders) in all;
                               // 0: defaults
@@ -736,6 +737,11 @@ int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, cons
         }
     }
     if constexpr (std::is_same<ST, float>::value && !INST && C == 32) {
+        if (acc == kAccSplit) {
+            launch_accumulate_split(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
+                                    n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st);
+            return finish();
+        }
         if (acc == kAccF32) {
             launch_accumulate_f32(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
                                   n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st);

@@ -101,6 +101,15 @@ void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes
 #undef BOXATTN_ACC_TR
 }
 
+void launch_accumulate_split(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
+                             const int4 *items, const int *n_items, const int *records, float *grad_value,
+                             float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,
+                             hipStream_t st)
+{
+    hipLaunchKernelGGL((binned_accumulate_split_kernel<32>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st, grad_out,
+                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc, zr);
+}
+
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                            const int4 *items, const int *n_items, const int *records, float *grad_value,
                            float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,

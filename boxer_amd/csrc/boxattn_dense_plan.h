@@ -103,6 +103,13 @@ void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes
                           uint16_t *grad_value, float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc,
                           const ZeroRole &zr, hipStream_t st);
 
+// float32 storage, C = 32: the accumulate on the bf16 matrix cores with exact three-term splits (boxattn_binned_tr.h:
+// binned_accumulate_split_kernel); grad_out below 2 GB
+void launch_accumulate_split(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
+                             const int4 *items, const int *n_items, const int *records, float *grad_value,
+                             float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,
+                             hipStream_t st);
+
 // float32 storage, C = 32: the accumulate on v_mfma_f32_32x32x2_f32 (boxattn_binned_tr.h); grad_out below 2 GB
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                            const int4 *items, const int *n_items, const int *records, float *grad_value,

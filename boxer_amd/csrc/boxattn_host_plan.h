@@ -31,17 +31,20 @@ inline int bin_chunk(const Dims &d)
 //            uniformly random ones;
 //   kAccValu everything else (float32, instance attention): binned_accumulate_kernel, 4-byte records, queries
 //            interleaved over the bin workgroups.
-enum AccKind { kAccValu = 0, kAccTr = 1, kAccF32 = 2 };
+//   kAccSplit float32 box attention, C = 32 (default): binned_accumulate_split_kernel -- the bf16 matrix cores on exact
+//            three-term splits of rows and weights, 16-byte records; boxattn_set_option(19, 1) goes back to kAccValu.
+enum AccKind { kAccValu = 0, kAccTr = 1, kAccF32 = 2, kAccSplit = 3 };
 inline bool accumulate_tr_ok(const Dims &d)          // 32-bit row offsets: grad_out below 2 GB
 {
     return (d.C == 16 || d.C == 32 || d.C == 64) && (size_t)d.B * d.Lq * d.H * d.C * 2 < kAccTrMaxBytes &&
            d.Lq < (1 << 24) && d.H * d.C * 2 < (1 << 24);
 }
-inline bool f32_mfma_ok(const Dims &d)
+inline bool f32_matrix_shape_ok(const Dims &d)
 {
-    return opt(kOptAccF32) == 2 && d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes &&
-           d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
+    return d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes && d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
 }
+inline bool f32_mfma_ok(const Dims &d) { return opt(kOptAccF32) == 2 && f32_matrix_shape_ok(d); }
+inline bool f32_split_ok(const Dims &d) { return opt(kOptAccF32) == 0 && f32_matrix_shape_ok(d); }
 template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
 {
     if constexpr (!INST && std::is_same<ST, bf16_t>::value) {
@@ -49,6 +52,7 @@ template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
     }
     if constexpr (!INST && std::is_same<ST, float>::value) {
         if (f32_mfma_ok(d)) return kAccF32;
+        if (f32_split_ok(d)) return kAccSplit;
     }
     return kAccValu;
 }
@@ -56,7 +60,7 @@ template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
 // whenever a flavour of that type may write them
 inline bool wide_workspace(bool is_bf16, const Dims &d)
 {
-    return is_bf16 ? accumulate_tr_ok(d) : f32_mfma_ok(d);
+    return is_bf16 ? accumulate_tr_ok(d) : f32_mfma_ok(d) || f32_split_ok(d);
 }
 constexpr int kMaxBlocks = 8192;      // per (image, head) slice: one LDS int each in bin_kernel
 

@@ -237,22 +237,24 @@ def test_box_backward_algorithms(cfg, dtype, variant):
     close(ga, want[2], torch.float32, "grad_attn")
 
 
-OPT_ACC_F32 = 19        # boxattn_set_option: 2 = float32 accumulate on v_mfma_f32_32x32x2_f32 (opt-in)
+OPT_ACC_F32 = 19        # boxattn_set_option: float32 accumulate -- 0 default: bf16 matrix cores on exact three-term splits,
+                        # 1: VALU list walk, 2: v_mfma_f32_32x32x2_f32
 
 
 @pytest.mark.parametrize("with_plan", [False, True], ids=["own_binning", "forward_plan"])
 @pytest.mark.parametrize("cfg", [FAST_CFGS[0], FAST_CFGS[1], FAST_CFGS[4], FAST_CFGS[5], SEEDED[6]],
                          ids=["0", "1", "4", "5", "6"])
 def test_float32_matrix_core_accumulate(cfg, with_plan):
-    """float32 grad_value (32 channels per head) from float32 MFMAs against the oracle at the float32 tolerance
-    and against the VALU kernel to summation-order rounding."""
+    """float32 grad_value (32 channels per head) from the matrix cores -- bf16 MFMAs on exact three-term splits (the
+    default) and float32 MFMAs -- against the oracle at the float32 tolerance and against the VALU kernel to
+    summation-order rounding."""
     from boxer_amd import _lib, ops
     g = _seeded(*cfg, seed=37, lo=-0.2, hi=1.2)
     want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])
     value, loc, attn = dev(g["value"], torch.float32), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
     shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], torch.float32)
     res = {}
-    for mode in (2, 1):
+    for mode in (0, 2, 1):
         old = _lib.load().boxattn_set_option(OPT_ACC_F32, mode)
         try:
             if with_plan:
@@ -266,6 +268,44 @@ def test_float32_matrix_core_accumulate(cfg, with_plan):
         res[mode] = gv
         close(gv, want[0], torch.float32, "grad_value (float32 accumulate %d)" % mode)
     assert (res[2] - res[1]).abs().max().item() <= 1e-5 * max(1.0, res[1].abs().max().item())
+    assert (res[0] - res[1]).abs().max().item() <= 1e-5 * max(1.0, res[1].abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["split_bf16_mfma", "valu", "f32_mfma"])
+def test_float32_accumulate_single_terms(mode):
+    """One point per (query, head) on a map with one query: every grad_value element is ONE product (hh hw a) g.  The
+    default float32 accumulate runs on the bf16 matrix cores with rows and weights split into three bf16 terms each
+    (exact splits; the six partial products above 2^-24 of the product): its result must be the float32 product to
+    within 2 ulp -- float32 arithmetic, not a 16-bit approximation of it (a two-term split of the weights alone
+    would be off by 2^-17, i.e. 64 ulp)."""
+    from boxer_amd import _lib
+    rng = np.random.default_rng(4321)
+    C = 32
+    # a power-of-two map and locations on a 2^-10 grid: pixel coordinates, bilinear fractions and their products are
+    # exact in float32 (the kernels form them in float32, the oracle in float64 -- on a general map the two differ by
+    # the rounding of loc * size - 0.5, hundreds of ulp of a small fraction, whatever the accumulate does)
+    shapes = np.asarray([(8, 16)], dtype=np.int64)
+    B, H, Lq, P = 2, 8, 1, 1
+    S = int(shapes.prod(1).sum())
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    g = dict(shapes=shapes, lsi=np.zeros(1, dtype=np.int64),
+             value=f32(rng.standard_normal((B, S, H, C))),
+             loc=rng.integers(128, 896, (B, Lq, H, 1, P, 2)).astype(np.float64) / 1024 + 1.0 / 4096,
+             attn=f32(rng.uniform(0.2, 1.0, (B, Lq, H, 1, P))),
+             grad_out=f32(rng.standard_normal((B, Lq, H * C)) * rng.choice([1e-3, 1.0, 1e3], (B, Lq, H * C))))
+    want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"], g["grad_out"])[0]
+    old = _lib.load().boxattn_set_option(OPT_ACC_F32, mode)
+    try:
+        _, gv, _, _ = run_box(g, torch.float32, "binned")
+    finally:
+        _lib.load().boxattn_set_option(OPT_ACC_F32, old)
+    got = gv.double().cpu().numpy()
+    nz = want != 0
+    assert nz.sum() == B * H * 4 * C and (got[~nz] == 0).all()
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(want[nz]))) - 23)
+    worst = (np.abs(got[nz] - want[nz]) / ulp).max()
+    # (weight = (hh hw) a: one float32 rounding in the kernels, none in the oracle; then the product with g)
+    assert worst <= 3.0, "worst error %.2f ulp" % worst
 
 
 @pytest.mark.parametrize("variant", ["atomic", "binned"])
