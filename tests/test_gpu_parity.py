@@ -1383,19 +1383,19 @@ def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, 
         err = (out.float() - plain.float()).abs().max().item()
         assert err <= 2.0 ** -7 * max(1.0, plain.float().abs().max().item())
     else:
-        assert torch.equal(out, plain)
+        # float32 encoder shapes (round 5): box_attn_forward takes the window-staged float32 forward, the fused call the
+        # row-gather kernel -- the same float32 products summed in another order
+        err = (out - plain).abs().max().item()
+        assert err <= 1e-5 * max(1.0, plain.abs().max().item())
     fused = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr,
                                            angle_mode, need_ref_grad=True)
     assert fused is not None, "the fused backward should take this shape"
     gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, grid, attn, gout, 64)
     go, rows = ops.box_grid_backward(ref, off, kidx, vr, angle_mode, gl, need_ref_grad=True)
     torch.cuda.synchronize()
-    if dtype == torch.bfloat16:
-        # bf16 encoder shapes: box_attn_backward takes the window-staged point-gradient kernel, the
-        # fused entry point the gather kernel -- same products, another order of the 32-term sums
-        assert (fused[3] - ga).abs().max().item() <= 2e-5 * max(1.0, ga.abs().max().item())
-    else:
-        assert torch.equal(fused[3], ga)
+    # encoder shapes (bf16, and float32 since round 5): box_attn_backward takes the window-staged point-gradient
+    # kernel, the fused entry point the gather kernel -- same products, another order of the 32-term sums
+    assert (fused[3] - ga).abs().max().item() <= 2e-5 * max(1.0, ga.abs().max().item())
     # (grad_value: same kernels, but the summation order inside a bin differs from run to run)
     for got, want, name in ((fused[0].float(), gv.float(), "grad_value"), (fused[1], go, "grad_offsets"),
                             (fused[2], rows, "grad_ref_rows")):

@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
