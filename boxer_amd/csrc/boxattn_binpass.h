@@ -152,7 +152,8 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
 // riders
 // ---------------------------------------------------------------------------------------
 enum { kRideWide = 1, kRideInterleave = 2, kRidePt4 = 4 };
-constexpr int kRideMaxBlocks = 1024;      // blocks per slice the riders' LDS histogram is built for (= kScanThreads)
+constexpr int kRideMaxBlocks = 3072;      // blocks per slice the riders' LDS histogram is built for (12 KB; beyond kScanThreads the
+                                          // slice's last arriver scans in two passes over it: scan_blocks_big_body)
 constexpr int kRideLdsInts = kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 4 * 4 + 2;
 
 // What a rider needs: the arguments of bin_kernel + the scan's outputs.  Passed BY VALUE all the way (a
@@ -230,13 +231,15 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
     const ScanOut o{r.subtot, r.offsets, r.items, r.combos, r.n_items};
     if (n_sub == 1) {        // one sub-range: its last arriver is the slice's, and does both scan stages in one pass
         RIDE_STAMP(3);
-        scan_blocks_body<THREADS>(o, plan, m.lv, 1, s, m.wsum, r.part, r.n_wg);
+        if (plan.nblk <= kScanThreads) scan_blocks_body<THREADS>(o, plan, m.lv, 1, s, m.wsum, r.part, r.n_wg);
+        else scan_blocks_big_body<THREADS>(o, plan, m.lv, 1, s, m.wsum, m.hist, r.part, r.n_wg);
     } else {
         scan_sub_body<THREADS>(r.part, r.subtot, plan, r.n_wg, s, u);
         stores_left();
         RIDE_STAMP(3);
         if (!last_arriver<THREADS>(tk + kScanSub, n_sub, m.flag)) return;
-        scan_blocks_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum);
+        if (plan.nblk <= kScanThreads) scan_blocks_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum);
+        else scan_blocks_big_body<THREADS>(o, plan, m.lv, n_sub, s, m.wsum, m.hist);
     }
     RIDE_STAMP(4);
 }

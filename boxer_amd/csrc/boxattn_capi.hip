@@ -1070,7 +1070,8 @@ const char *boxattn_build_info(void)
 {
     return "boxattn gfx950 (CDNA4, wave64) | hipcc " __VERSION__
            " | kernels: generic{f32,f64,bf16}, gather{f32 4ch/lane, bf16 8ch/lane} C={16,32,64}, "
-           "window-staged encoder forward + point gradients{bf16, MFMA 4x4x4}, binned-bwd{f32, bf16 on MFMA 32x32x16} "
+           "window-staged encoder forward + point gradients{bf16 on MFMA 4x4x4, f32 on VALU}, "
+           "binned-bwd{bf16 on MFMA 32x32x16, f32 on the same MFMA over exact three-term bf16 splits} "
            "with count / scan / fill / combine riding in the forward, point-gradient and accumulate launches, "
            "box-grid{f32} | abi 7";
 }

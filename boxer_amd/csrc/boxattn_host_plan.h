@@ -129,9 +129,9 @@ inline bool make_plan_blocks(const Dims &d, const int64_t *sh, const int64_t *ls
     p.item_cap = (int)(blk0 + rec_cap / p.chunk + 1);
     // sparse maps (fewer than ~2 expected records per block -- the BEV decoders: 1 000 queries against 468 x 468):
     // grad_value is zero-filled once and the empty blocks get no work item (BinPlan::min_items)
-    // (only where the riders cannot run anyway: such a plan is always built by launch_binning, which also fills the
-    // zero workers' geometry table)
-    p.min_items = blk0 > kRideMaxBlocks && 3ll * d.Lq * d.L * d.P / 2 < 2 * blk0 ? 0 : 1;
+    // (such a plan is always built by launch_binning, which also fills the zero workers' geometry table: riders_ok
+    // refuses it)
+    p.min_items = blk0 > kScanThreads && 3ll * d.Lq * d.L * d.P / 2 < 2 * blk0 ? 0 : 1;
     p.zero_workers = p.min_items ? 0 : (int)((blk0 + kZeroPer - 1) / kZeroPer);
     // blocks with more than one chunk: sum of their chunk counts <= 2 * records / chunk
     p.pslot_cap = (int)std::min<long long>(2 * (rec_cap / p.chunk) + 2, blk0 + rec_cap / p.chunk + 1);
@@ -212,7 +212,8 @@ constexpr size_t kStatBytes = (size_t)kDenseStatSlots * 2 * sizeof(unsigned long
 // May the count / fill passes and the scans of this plan run as riders (boxattn_ride.h)?
 inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
 {
-    return opt(kOptRiders) != 1 && plan.nblk <= kRideMaxBlocks && w.n_wg <= kScanSub * kScanWgPerSub;
+    return opt(kOptRiders) != 1 && plan.nblk <= kRideMaxBlocks && plan.min_items == 1 &&
+           w.n_wg <= kScanSub * kScanWgPerSub;
 }
 
 // ------------------------------------------------- window-staged encoder kernels (boxattn_dense.h)

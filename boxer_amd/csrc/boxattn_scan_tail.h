@@ -181,6 +181,100 @@ __device__ __forceinline__ void scan_blocks_body(const ScanOut o, const BinPlan 
     }
 }
 
+// The same scan for slices with more blocks than scan_blocks_body's threads hold in registers (kScanThreads < nblk <=
+// kRideMaxBlocks: the BEV encoder's 234 x 234 + 117 x 117 = 2 220 blocks): two passes over `cnt`, nblk ints of LDS -- the
+// count rider's histogram, free once its row of counts has left.  Pass 1 (block = thread + i THREADS: coalesced rows)
+// brings every block's total into LDS and turns the bin workgroups' / sub-ranges' counts into first slots in place;
+// pass 2 (`per` consecutive blocks per thread) is the scan and the emit of scan_blocks_body with the totals read from LDS.
+template <int THREADS>
+__device__ __forceinline__ void scan_blocks_big_body(const ScanOut o, const BinPlan &plan, const BinLevel *lv_lds,
+                                                     int n_sub, int s, int *wsum, int *cnt,
+                                                     int *fuse_part = nullptr, int fuse_wg = 0)
+{
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __syncthreads();                               // every wave has published its part of the histogram
+    for (int k = tid; k < plan.nblk; k += THREADS) {
+        int c = 0;
+        if (fuse_part) {
+            int *sp = fuse_part + (size_t)s * fuse_wg * plan.nblk + k;
+            int tv[kScanWgPerSub];
+#pragma unroll
+            for (int w = 0; w < kScanWgPerSub; ++w) tv[w] = w < fuse_wg ? agent_load(sp + (size_t)w * plan.nblk) : 0;
+#pragma unroll
+            for (int w = 0; w < kScanWgPerSub; ++w) {
+                if (w < fuse_wg) sp[(size_t)w * plan.nblk] = c;
+                c += tv[w];
+            }
+            o.subtot[(size_t)s * kScanSub * plan.nblk + k] = 0;
+        } else {
+            int tv[kScanSub];
+#pragma unroll
+            for (int uu = 0; uu < kScanSub; ++uu)
+                tv[uu] = uu < n_sub ? agent_load(o.subtot + ((size_t)s * kScanSub + uu) * plan.nblk + k) : 0;
+#pragma unroll
+            for (int uu = 0; uu < kScanSub; ++uu) {
+                if (uu < n_sub) o.subtot[((size_t)s * kScanSub + uu) * plan.nblk + k] = c;
+                c += tv[uu];
+            }
+        }
+        cnt[k] = c;
+    }
+    __syncthreads();
+    const int per = (plan.nblk + THREADS - 1) / THREADS;
+    const int k_lo = min(tid * per, plan.nblk), k_hi = min(k_lo + per, plan.nblk);
+    int sum[4] = {0, 0, 0, 0};
+    for (int k = k_lo; k < k_hi; ++k) {
+        const int c = cnt[k], nch = max(plan.min_items, (c + plan.chunk - 1) / plan.chunk);
+        sum[0] += c; sum[1] += nch; sum[2] += nch > 1 ? nch : 0; sum[3] += nch > 1 ? 1 : 0;
+    }
+    int run[4], tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x = sum[i];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        run[i] = x - sum[i];
+        if (lane == 63) wsum[i * NW + wv] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            pre += w < wv ? wsum[i * NW + w] : 0;
+            all += wsum[i * NW + w];
+        }
+        run[i] += pre;
+        tot[i] = all;
+    }
+    for (int k = k_lo; k < k_hi; ++k) {
+        const int c = cnt[k], nch = max(plan.min_items, (c + plan.chunk - 1) / plan.chunk);
+        o.offsets[(size_t)s * (plan.nblk + 1) + k] = run[0];
+        int level = 0;
+        for (int l = 1; l < plan.L; ++l)
+            if (k >= lv_lds[l].blk0) level = l;
+        const BinLevel lv = lv_lds[level];
+        const int geo = (int)pack_block_geo(lv, level, k);
+        const int csz = chunk_records(c, nch);
+        for (int jj = 0; jj < nch; ++jj)
+            o.items[(size_t)s * plan.item_cap + (tot[1] - 1 - (run[1] + jj))] =
+                make_int4(geo, run[0] + jj * csz, run[0] + min(c, (jj + 1) * csz),
+                          nch > 1 ? (run[2] + jj) | (run[3] << kItemSlotBits) : -1);
+        if (nch > 1) o.combos[(size_t)s * plan.nblk + run[3]] = make_int4(geo, run[2], nch, 0);
+        run[0] += c; run[1] += nch; run[2] += nch > 1 ? nch : 0; run[3] += nch > 1 ? 1 : 0;
+    }
+    if (tid == 0) {
+        o.offsets[(size_t)s * (plan.nblk + 1) + plan.nblk] = tot[0];
+        o.n_items[2 * s] = tot[1];
+        o.n_items[2 * s + 1] = tot[3];
+    }
+}
+
 // Sparse maps (BinPlan::min_items == 0: far more blocks than records -- 1 000 queries against a 468 x 468 BEV
 // map): the blocks without records get no work item; their rows of grad_value are zeroed by ZERO WORKERS, extra
 // single-wave workgroups in front of the accumulate launch's grid.  A zero worker takes `per` consecutive blocks

@@ -340,25 +340,28 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *  10  binned backward: records per work item (multiple of 64; default: from the number of sample
  *      points, 128 ... 1024).  Set it before boxattn_plan_bytes / boxattn_bwd_workspace_bytes: the
  *      layouts depend on it.
- *  11  window-staged point-gradient kernel of the encoder case (bf16 box attention, Lq == S, C = 32,
- *      2x2 points, <= 4 levels): 0 library default (on), 1 off (row-gather kernel), 2 on
+ *  11  window-staged kernels of the encoder case (box attention, bf16 or float32 storage, Lq == S, C = 32,
+ *      2x2 points, <= 4 levels): 0 library default (on), 1 off (row-gather kernels), 2 on
  *  12  ... margin of its staged windows for the predicted box offsets, in tenths of a quarter of the
  *      expected box (0 = default 25); 13 ... expected box size in pixels of the query's own level
  *      (0 = default 4, BoxeR's reference windows).  Placement only: results do not depend on them.
  *  15  riders: the count pass + scans inside the training forward's launch, the fill pass
  *      inside the point-gradient launch, chunked blocks summed inside the accumulate launch:
  *      0 default (on; chunked blocks are summed inside the accumulate launch wherever the riders run -- maps of up
- *      to 1 024 blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head), and by a
+ *      to 3 072 blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head), and by a
  *      combine launch behind it otherwise), 1 off (launches of their own), 2 on with the combine always a launch of
  *      its own, 3 on with the combine always inside
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
- *  19  float32 storage, 32 channels per head: grad_value accumulate on v_mfma_f32_32x32x2_f32 (float32 operands
- *      and accumulation, 16-byte records): 0 / 1 off (default), 2 on.
+ *  19  float32 box attention, 32 channels per head: the grad_value accumulate -- 0 default: the bf16 matrix cores on
+ *      exact three-term splits of rows and weights (float32-accurate, 16-byte records), 1: VALU list
+ *      walk (4-byte records), 2: v_mfma_f32_32x32x2_f32 (16-byte records).
  *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
  *  20  where the riders sit in their host kernel's grid: (s_count + 1) | (s_fill + 1) << 4 -- a group of 8
  *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | v << 8: 64 v bin workgroups
  *      (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
+ *  21  window-staged FLOAT32 kernels of the encoder case (three workgroups per CU): 0 default (on), 1 off (row-gather
+ *      kernels; 11 = 1 switches both storage types off)
  */
 int boxattn_set_option(int key, int value);
 /* Number of boxattn_set_variant / boxattn_set_option calls so far: lets a binding cache the size queries

@@ -226,8 +226,9 @@ def test_rider_placement_does_not_change_results(shift, dense_switch):
         assert worst <= tol, (shift, name, worst)
 
 
+@pytest.mark.parametrize("workload", ["C2", "bev_encoder", "bev_1000_queries"])
 @pytest.mark.parametrize("fwd", [2, 1], ids=["staged_fwd", "gather_fwd"])
-def test_riders_match_the_stand_alone_passes(fwd, monkeypatch):
+def test_riders_match_the_stand_alone_passes(fwd, workload, monkeypatch):
     """The training step with the count pass + scans riding in the forward kernel's launch, the fill pass
     in the point-gradient kernel's and the chunked blocks combined inside the accumulate launch, against
     the same passes as launches of their own: same plan -- compared through what the backward makes of it
@@ -239,20 +240,36 @@ def test_riders_match_the_stand_alone_passes(fwd, monkeypatch):
     # uniformly random locations at this shape would have the first calls run on the gather kernels)
     monkeypatch.setattr(ops._Locality, "enabled", False)
     old_fwd = lib.boxattn_set_option(OPT_DENSE_FWD, fwd)
+    # 2 220 blocks per slice (234 x 234 + 117 x 117, BoxeR-3D): more than the one-pass block scan holds -- the riders'
+    # last arriver scans in two passes over the histogram's LDS (scan_blocks_big_body), behind 8 sub-ranges of bin
+    # workgroups (the encoder) or fused with the one bin workgroup's counts (1 000 queries)
+    monkeypatch.setitem(bench.WORKLOADS, "bev_encoder", bench.WORKLOADS["C5p"])
+    monkeypatch.setitem(bench.WORKLOADS, "bev_1000_queries", ([(234, 234), (117, 117)], 1000, 4, "box3d"))
+    if workload != "C2" and fwd == 1:
+        pytest.skip("one forward flavour is enough for the block-scan variants")
+    steps = 60 if workload == "C2" else 24
     for dtype in (torch.bfloat16, torch.float32):
-        inp = bench.make_inputs("C2", dtype, "cuda", family="model", batch=2, seed=1)
+        inp = bench.make_inputs(workload, dtype, "cuda", family="model", batch=2 if workload == "C2" else 1, seed=1)
         v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
         res = {}
         for mode in (1, 0, 3):           # own launches | riders (combine: own launch at this size) | riders, combine inside
             old = lib.boxattn_set_option(OPT_RIDERS, mode)
             try:
                 outs = []
-                for it in range(2 if mode == 1 else 60):
+                for it in range(2 if mode == 1 else steps):
                     out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
                     gv, gl, ga = ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
                     outs.append((out, gv, gl, ga))
                 torch.cuda.synchronize()
                 res[mode] = outs
+                # which passes were launches of their own in one more step (the library's per-kernel event slots)
+                from boxer_amd import _lib as blib
+                blib.profile_begin()
+                out, plan = ops.box_attn_forward_train(v, sh, ls, loc, attn, 64)
+                ops.box_attn_backward(v, sh, ls, loc, attn, go, 64, plan=plan)
+                torch.cuda.synchronize()
+                launches = {k: v["launches"] for k, v in blib.profile_end().items()}
+                assert (launches["bwd_binning"] > 0) == (mode == 1), (mode, launches)
             finally:
                 lib.boxattn_set_option(OPT_RIDERS, old)
         ref = res[1][0]

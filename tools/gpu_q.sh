@@ -1,4 +1,13 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
+run() { # workload dtype opt
+timeout 300 python bench.py --workload $1 --dtype $2 --steps 1500 --warmup 100 --rotate 0 --no-cpu-baseline --opt 15=$3 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']
+        print('$1 $2 opt15=$3', d['ms_per_step'], {k: v['avg_ms'] for k, v in r['kernels'].items()})
+"; }
+for o in 0 2 1 0 2; do run C5p bf16 $o; done
+for o in 0 2 1; do run C5p fp32 $o; done
