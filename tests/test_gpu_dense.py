@@ -54,7 +54,7 @@ def binning(request):
     lib.boxattn_set_option(OPT_RIDERS, old)
 
 
-def make_case(levels, family, H=8, B=2, seed=0):
+def make_case(levels, family, H=8, B=2, seed=0, dtype=torch.bfloat16):
     """bench.make_inputs for an ad-hoc encoder shape; extra families on top of "model" / "test":
     "mixed" = model-like with every 7th box thrown far away, "border" = locations in [-0.2, 1.2]."""
     name = "_dense_test"
@@ -63,7 +63,7 @@ def make_case(levels, family, H=8, B=2, seed=0):
     bench.H_HEADS = H
     try:
         base = "model" if family in ("model", "mixed") else "test"
-        inp = bench.make_inputs(name, torch.bfloat16, "cuda", family=base, batch=B, seed=seed)
+        inp = bench.make_inputs(name, dtype, "cuda", family=base, batch=B, seed=seed)
     finally:
         bench.H_HEADS = old_h
         del bench.WORKLOADS[name]
@@ -109,6 +109,37 @@ def test_dense_kernels_match_oracle(lv, family, dense_switch, binning, forward_k
     out, grads = run(inp)
     for name, worst, tol in bench.parity_report(inp, out, grads):
         assert worst <= tol, "%s/%s %s: worst %.3e > %.0e" % (lv, family, name, worst, tol)
+
+
+OPT_ACC_F32 = 19        # float32 accumulate: 0 bf16 matrix cores on exact three-term splits; 1 VALU; 2 float32 MFMAs
+OPT_DENSE_F32 = 21      # window-staged float32 kernels: 0 on, 1 off
+
+
+@pytest.mark.parametrize("acc", [0, 1, 2], ids=["split_bf16_mfma", "valu", "f32_mfma"])
+@pytest.mark.parametrize("family", ["model", "test", "mixed", "border"])
+@pytest.mark.parametrize("lv", sorted(LEVELS))
+def test_float32_staged_kernels_match_oracle(lv, family, acc, binning):
+    """float32 storage -- the reference's own arithmetic (box_attention_func.py:11) -- through the window-staged float32
+    forward / point-gradient kernels and every flavour of the float32 accumulate, against the oracle at the float32
+    tolerance; the staged and the row-gather kernels agree to float32 rounding."""
+    lib = _lib()
+    inp = make_case(LEVELS[lv], family, dtype=torch.float32)
+    old = lib.boxattn_set_option(OPT_ACC_F32, acc)
+    try:
+        out, grads = run(inp)
+        for name, worst, tol in bench.parity_report(inp, out, grads):
+            assert worst <= tol, "%s/%s %s: worst %.3e > %.0e" % (lv, family, name, worst, tol)
+        if acc == 0 and binning == 0:
+            old21 = lib.boxattn_set_option(OPT_DENSE_F32, 1)
+            try:
+                out_g, grads_g = run(inp)
+            finally:
+                lib.boxattn_set_option(OPT_DENSE_F32, old21)
+            for name, a, b in zip(("out", "grad_value", "grad_loc", "grad_attn"), (out,) + tuple(grads), (out_g,) + tuple(grads_g)):
+                scale = max(1.0, b.abs().max().item())
+                assert (a - b).abs().max().item() <= 2e-5 * scale, (lv, family, name)
+    finally:
+        lib.boxattn_set_option(OPT_ACC_F32, old)
 
 
 @pytest.mark.parametrize("seed", range(10))
