@@ -32,6 +32,9 @@ namespace boxattn {
 #ifndef BOXATTN_TUNE_TR_WPE
 #define BOXATTN_TUNE_TR_WPE 4
 #endif
+#ifndef BOXATTN_TUNE_REC_AHEAD
+#define BOXATTN_TUNE_REC_AHEAD 1       // float32 kernel: request the next item's first records while the current item is summed
+#endif
 
 typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float tr_f32x16 __attribute__((ext_vector_type(16)));
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
             for (int ps = 0; ps < NPASS; ++ps)
                 *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(gs) + stage_off + ps * RPP * 64) = rows[ps];
         };
+        // (requesting the NEXT item's first records here -- an item starts with two dependent round trips, and a
+        // level-0 block at BoxeR-R50 shapes is under four rounds -- costs this kernel seven spilled registers and
+        // 1-3 %; the float32 kernel below, which has the registers, gains 1 % from it)
         int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
         u32x4 grow_a[NPASS], grow_b[NPASS];
         fetch_rows(rec_c, grow_a);
@@ -368,6 +374,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     const int4 *my_items = items + (size_t)s * plan.item_cap;
     int4 item_n = my_items[min(worker, plan.item_cap - 1)];
+    // (the next item's first records are requested while the current item is summed: an item starts with two dependent
+    // round trips -- its records, then the rows they name -- in front of its first product; C2 float32 step -1 %)
+    const int4 *rec_s = reinterpret_cast<const int4 *>(records) + (size_t)s * plan.rec_cap;
+    int4 rec_first = make_int4(-1, 0, 0, 0);
+    if (BOXATTN_TUNE_REC_AHEAD && worker < n_it && item_n.y + lane < item_n.z) rec_first = rec_s[item_n.y + lane];
     for (int it = worker; it < n_it; it += workers) {
         const int4 item = item_n;
         item_n = my_items[min(it + workers, plan.item_cap - 1)];
@@ -404,8 +415,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             x1 -= __uint_as_float(pk & 0xffff0000u);
             return pk;
         };
-        int4 rec_c = fetch_rec(item.y), rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
+        int4 rec_c = BOXATTN_TUNE_REC_AHEAD ? rec_first : fetch_rec(item.y);
+        int4 rec_n = fetch_rec(item.y + R), rec_n2 = fetch_rec(item.y + 2 * R);
         fetch_rows(rec_c);
+        if (BOXATTN_TUNE_REC_AHEAD) {
+            rec_first = make_int4(-1, 0, 0, 0);
+            if (it + workers < n_it && item_n.y + lane < item_n.z) rec_first = rec_s[item_n.y + lane];
+        }
         for (int rr = item.y; rr < item.z; rr += R) {
             const bool more = rr + R < item.z;         // wave-uniform
             int4 rec_n3 = make_int4(-1, 0, 0, 0);
