@@ -249,7 +249,7 @@ def set_variant(v):
 
 
 OPTIONS = {"bin_chunk": 10, "dense": 11, "dense_jit": 12, "dense_ref": 13, "riders": 15, "dense_fwd": 17,
-           "acc_f32": 19, "ride_shift": 20}
+           "acc_f32": 19, "ride_shift": 20, "dense_f32": 21}
 
 
 def set_option(name, value):

@@ -39,3 +39,10 @@ def _fresh_kernel_choice():
         ops._LOCALITY.clear()
         ops._PARKED.clear()          # (plans parked by a forward whose backward a test never ran)
     yield
+    # ... and no test inherits a library switch another one left set (a skip or a failed assertion between a test's
+    # boxattn_set_option calls): every option and the kernel variant back to the defaults
+    lib = sys.modules.get("boxer_amd._lib")
+    if lib is not None and lib._lib is not None:
+        for key in lib.OPTIONS.values():
+            lib._lib.boxattn_set_option(key, 0)
+        lib._lib.boxattn_set_variant(0)

@@ -1,7 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for i in 1 2; do
-VARIANT_DTYPES="bf16 fp32" bash tools/gpu_variants.sh --workload C2 --rotate 0 --steps 1500 --warmup 100
-cp gpurun_out/variants.log gpurun_out/variants_c2_$i.log
-done
-VARIANT_DTYPES="bf16 fp32" bash tools/gpu_variants.sh --workload C2p --rotate 0 --steps 1000 --warmup 100
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests/test_gpu_dense.py -m gpu -q -x 2>&1 | tail -60 | tee gpurun_out/q_pytest.log

@@ -31,6 +31,12 @@ bash tools/gpu_pmc_multi.sh r05sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_
   "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" > /dev/null 2>&1
 python tools/sq_summary.py gpurun_out/pmc_r05sq_1 gpurun_out/pmc_r05sq_2 gpurun_out/pmc_r05sq_3 > $R/pmc_sq.txt 2>&1
 rm -rf gpurun_out/pmc_r05sq_1 gpurun_out/pmc_r05sq_2 gpurun_out/pmc_r05sq_3
+# ... and of the float32 step
+bash tools/gpu_pmc_multi.sh r05sqf "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
+  "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+  "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" -- --dtype fp32 > /dev/null 2>&1
+python tools/sq_summary.py gpurun_out/pmc_r05sqf_1 gpurun_out/pmc_r05sqf_2 gpurun_out/pmc_r05sqf_3 > $R/pmc_sq_fp32.txt 2>&1
+rm -rf gpurun_out/pmc_r05sqf_1 gpurun_out/pmc_r05sqf_2 gpurun_out/pmc_r05sqf_3
 # switches, one at a time against the default (boxattn_set_option key=value)
 for o in "" "15=1" "15=2" "17=1" "11=1"; do
   for inp in model test; do
@@ -40,5 +46,13 @@ import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']
 print('Gpts/s', d['value'], 'us/step', round(1000 * d['ms_per_step'], 1), {k: round(1000 * v['avg_ms'], 1) for k, v in r['kernels'].items()})" >> $R/ab_switches.log
   done
+done
+# float32 switches: accumulate flavour (19), window-staged kernels (21)
+for o in "" "19=1" "19=2" "21=1" "15=1"; do
+  echo -n "fp32 opt ${o:-default} : " >> $R/ab_switches.log
+  timeout 300 python bench.py --steps 300 --warmup 20 --no-cpu-baseline --rotate 0 --dtype fp32 ${o:+--opt $o} 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); r = d['roofline']
+print('Gpts/s', d['value'], 'us/step', round(1000 * d['ms_per_step'], 1), {k: round(1000 * v['avg_ms'], 1) for k, v in r['kernels'].items()})" >> $R/ab_switches.log
 done
 ls $R
