@@ -13,7 +13,8 @@ import sys
 SLOT = {"fwd2_kernel": "fwd", "fwd_dense_kernel": "fwd", "fwd_fast_kernel": "fwd", "pointgrad2_kernel": "bwd_points",
         "bwd_fast_kernel": "bwd_points", "binned_accumulate_kernel": "bwd_accumulate",
         "binned_accumulate_f32_kernel": "bwd_accumulate", "binned_accumulate_tr_kernel": "bwd_accumulate",
-        "pointgrad_dense_kernel": "bwd_points"}
+        "binned_accumulate_split_kernel": "bwd_accumulate", "pointgrad_dense_kernel": "bwd_points",
+        "fwd_dense_f32_kernel": "fwd", "pointgrad_dense_f32_kernel": "bwd_points"}
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                         "profiles", "hbm_traffic.json")
 res = json.load(open(out_path)) if os.path.exists(out_path) else {}
