@@ -1,4 +1,5 @@
-"""Soak of the default training step (riders, in-launch combine, direct-to-LDS staging): N back-to-back steps per
+"""Soak of the default training step (riders -- also on the BEV encoder's 2 220-block maps --, in-launch combine,
+direct-to-LDS staging, the float32 staged kernels and split accumulate): N back-to-back steps per
 workload and storage type; every step's out / grad_loc / grad_weights must be bit-identical to the first step's
 (they do not depend on any summation order) and grad_value within the storage type's tolerance of it.
     gpurun -- python tools/gpu_soak_step.py [steps]"""
@@ -14,7 +15,7 @@ from boxer_amd import ops  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 ops._Locality.enabled = False          # same kernels in every step
 bad = 0
-for wl in ("C2", "C2p", "C3", "C5pp"):
+for wl in ("C2", "C2p", "C3", "C5p", "C5pp"):
     for dtype in (torch.bfloat16, torch.float32):
         inp = bench.make_inputs(wl, dtype, "cuda", family="model", batch=2, seed=3)
         step = bench.make_step(inp, "ops")
