@@ -155,6 +155,14 @@ struct DenseWinPos {
 };
 
 typedef __attribute__((address_space(3))) void dense_lds_void;
+// timing experiments only (phase split of the tile kernels): the windows are not fetched (the arithmetic
+// runs on whatever the LDS holds) / the arithmetic is skipped (windows fetched, locations loaded, zeros stored)
+#ifndef BOXATTN_DEBUG_NO_STAGE
+#define BOXATTN_DEBUG_NO_STAGE 0
+#endif
+#ifndef BOXATTN_DEBUG_NO_MATH
+#define BOXATTN_DEBUG_NO_MATH 0
+#endif
 
 template <int L>
 __device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const DenseWin (&wrow)[L],
@@ -186,7 +194,7 @@ __device__ __forceinline__ void dense_stage_issue(const DenseHot<L> &hot, const 
         if (j < o.cols()) {
 #pragma unroll
             for (int k = 0; k < RPW; ++k) {
-                if (wv + 4 * k < rows)                                 // wave-uniform
+                if (wv + 4 * k < rows && !BOXATTN_DEBUG_NO_STAGE)      // wave-uniform
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (dense_lds_void *)(lds + dst), 16, voff, soff, 0, 0);
                 soff += 4u * row_bytes;
                 dst += step;
@@ -446,6 +454,11 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void pointgrad_dense_kernel
     float ga[L], gx[L], gy[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+        if (BOXATTN_DEBUG_NO_MATH) {                               // (timing experiments: loads kept, arithmetic gone)
+            asm volatile("" ::"v"(xy[l].x), "v"(xy[l].y), "v"(a[l]), "v"(gw[0]), "v"(gw[15]));
+            ga[l] = gx[l] = gy[l] = 0.f;
+            continue;
+        }
         const DenseMap T = hot.lv[l];
         const DensePoint s = dense_locate(xy[l].x, xy[l].y, T.H, T.W);
         float sk[4];

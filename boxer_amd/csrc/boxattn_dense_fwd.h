@@ -113,6 +113,10 @@ __global__ __launch_bounds__(256, BOXATTN_DENSE_WPE) void fwd_dense_kernel(
     for (int m = 0; m < 8; ++m) { acc[m] = fwd_f32x4{0.f, 0.f, 0.f, 0.f}; accv[m] = 0.f; }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
+        if (BOXATTN_DEBUG_NO_MATH) {                               // (timing experiments: loads kept, arithmetic gone)
+            asm volatile("" ::"v"(xy[l].x), "v"(xy[l].y), "v"(a[l]));
+            continue;
+        }
         const DenseMap T = hot.lv[l];
         const DenseWinPos &o = win[l];
         const DensePoint s = dense_locate(xy[l].x, xy[l].y, T.H, T.W);

@@ -1,4 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_gpu_dense.py -m gpu -q -x 2>&1 | tail -60 | tee gpurun_out/q_pytest.log
+for i in 1 2; do
+VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check --opt 15=1
+VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check
+done
