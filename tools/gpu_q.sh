@@ -1,10 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_dense.py -m gpu -q -x -k "riders_match or rider_placement or match_oracle" 2>&1 | tail -4
-for i in 1 2; do
-VARIANT_DTYPES="bf16 fp32" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check
-VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check --opt 15=1
-done
-VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C5p --rotate 0 --no-check
-VARIANT_DTYPES="fp32" bash tools/gpu_variants.sh --workload C3 --rotate 0 --no-check
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee gpurun_out/pytest_gpu.log
+bash tools/gpu_train_steps.sh 2>&1 | tail -12
