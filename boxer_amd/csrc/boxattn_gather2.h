@@ -581,13 +581,14 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     }
     const unsigned blk = role.id;
     __shared__ LevelTable lv;
-    load_levels(lv, shapes, lsi, L);
+    const LevelRegs lv_regs = levels_request(shapes, lsi, L);           // published below, behind the first loads
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     unsigned qh = blk * kGatherWaves + wv;                   // one pair per wave
     if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
         qh = ((blk / 8) * kGatherWaves + wv) * (unsigned)H + blk % 8;
-    if (qh >= ix.n_qh) return;                                          // wave-uniform
+    const bool live = qh < ix.n_qh;                                     // wave-uniform
+    qh = min(qh, ix.n_qh - 1u);
     const int slot = lane % G, grp = lane / G;
     unsigned bq, hu, b, qu;
     divmod_magic(qh, (unsigned)H, ix.magic_h, bq, hu);
@@ -605,9 +606,24 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
 #pragma unroll
     for (int i = 0; i < VEC / 2; ++i) acc[i] = f32x2{0.f, 0.f};
 
+    // The wave is a chain of round trips -- level table, locations, rows, per step of NG points -- and at 300
+    // queries the whole launch is ONE wave's life (1 200 workgroups: a single round): the location / weight loads of
+    // a step's first level group are requested a step ahead, the first step's in front of the level table's barrier.
+    struct Ahead { float2 xy; float as, al; };
+    auto request = [&](int p0) -> Ahead {
+        const int p = min(p0 + grp, P - 1), lc = min(slot, L - 1);
+        const size_t i = pt0 + (size_t)lc * P + p;
+        return Ahead{loc2[i], w_sp[i], w_lv[i]};
+    };
+    Ahead nxt = request(0);
+    levels_commit(lv, lv_regs, L);
+    if (!live) return;
+
     for (int p0 = 0; p0 < P; p0 += NG) {                              // wave-uniform trip count
         const int p = p0 + grp;
         const bool have_p = p < P;
+        const Ahead cur = nxt;
+        if (p0 + NG < P) nxt = request(p0 + NG);
         f32x2 macc[VEC / 2];
 #pragma unroll
         for (int i = 0; i < VEC / 2; ++i) macc[i] = f32x2{0.f, 0.f};
@@ -616,10 +632,16 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
             const int l = l0 + slot;
             const bool have = have_p && l < L;
             const int lc = min(l, L - 1);
-            const size_t i = pt0 + (size_t)lc * P + (have_p ? p : P - 1);
-            const float2 xy = loc2[i];
-            const float as = have ? w_sp[i] : 0.f;
-            const float al = have ? w_lv[i] : 0.f;
+            float2 xy = cur.xy;
+            float as = cur.as, al = cur.al;
+            if (l0 > 0) {                                              // (more levels than lanes in a group)
+                const size_t i = pt0 + (size_t)lc * P + (have_p ? p : P - 1);
+                xy = loc2[i];
+                as = w_sp[i];
+                al = w_lv[i];
+            }
+            as = have ? as : 0.f;
+            al = have ? al : 0.f;
             const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[lc], lv.w[lc]);
             const u32x4_t my_off =
                 corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[lc], H, h, C, have);
