@@ -9,10 +9,6 @@
 
 namespace boxattn {
 
-#ifndef BOXATTN_TUNE_COUNT_DUMP
-#define BOXATTN_TUNE_COUNT_DUMP 1      // count pass: per-lane dump slots instead of predicated LDS atomics
-#endif
-
 // One pass of workgroup `wg` of slice `s` over its queries' sample points: every point is assigned to the
 // <= 4 blocks its 2x2 footprint touches (touched_blocks).
 //   count (!FILL): per-block counts in the LDS histogram `hist` (left there; the caller writes them out);
@@ -100,7 +96,6 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
         else
             rec[slot] = id;
     };
-    const int dump = plan.nblk + (int)threadIdx.x;     // (count pass: `hist` has THREADS ints behind its nblk counters)
     auto work_step = [&](const Step &t, int g0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -117,12 +112,7 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
                 // per lane, a shared dump slot made this kernel 1.6x slower
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (!FILL && BOXATTN_TUNE_COUNT_DUMP) {
-                        // count: unused candidates add to the LANE's own dump slot behind the histogram -- an
-                        // unconditional atomic (select + ds_add) instead of one under an exec mask of its own
-                        // (compare, s_and_saveexec, ds_add, s_or: four candidates a point)
-                        atomicAdd(&hist[blk[j] >= 0 ? blk[j] : dump], 1);
-                    } else if (blk[j] >= 0) {
+                    if (blk[j] >= 0) {
                         const int slot = atomicAdd(&hist[blk[j]], 1);            // LDS
                         if constexpr (FILL) put_record(t, u, k, slot);
                     }
@@ -164,8 +154,7 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
 enum { kRideWide = 1, kRideInterleave = 2, kRidePt4 = 4 };
 constexpr int kRideMaxBlocks = 3072;      // blocks per slice the riders' LDS histogram is built for (12 KB; beyond kScanThreads the
                                           // slice's last arriver scans in two passes over it: scan_blocks_big_body)
-constexpr int kRideHistInts = kRideMaxBlocks + 256;     // ... + one dump slot per thread of the count pass
-constexpr int kRideLdsInts = kRideHistInts + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 4 * 4 + 2;
+constexpr int kRideLdsInts = kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 4 * 4 + 2;
 
 // What a rider needs: the arguments of bin_kernel + the scan's outputs.  Passed BY VALUE all the way (a
 // kernel-argument struct handed on by reference was copied to scratch at the top of every wave of the host
@@ -194,16 +183,16 @@ struct BinRide {
         }                                                                                           \
     } while (0)
 
-// LDS of a rider: [histogram: kRideMaxBlocks ints + 256 dump slots][level table][4 x 4 wave sums][flag]
+// LDS of a rider: [histogram: kRideMaxBlocks ints][level table][4 x 4 wave sums][flag]
 struct RideLds {
     int *hist;
     BinLevel *lv;
     int *wsum;
     int *flag;
     __device__ __forceinline__ explicit RideLds(int *base)
-        : hist(base), lv(reinterpret_cast<BinLevel *>(base + kRideHistInts)),
-          wsum(base + kRideHistInts + 8 * (int)(sizeof(BinLevel) / sizeof(int))),
-          flag(base + kRideHistInts + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 16) {}
+        : hist(base), lv(reinterpret_cast<BinLevel *>(base + kRideMaxBlocks)),
+          wsum(base + kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeof(int))),
+          flag(base + kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 16) {}
 };
 static_assert(kMaxBinLevels == 8, "RideLds reserves 8 levels");
 

@@ -557,7 +557,7 @@ inline void launch_binning(int flavour, const float *loc, const float *w_sp, con
     int *n_items = (int *)(pbuf + w.n_items), *offsets = (int *)(pbuf + w.offsets);
     int4 *items = (int4 *)(pbuf + w.items), *combos = (int4 *)(pbuf + w.combos);
     const dim3 bgrid(w.n_wg, ns);
-    const size_t bsh = ((size_t)plan.nblk + 1 + kBinThreads) * sizeof(int);    // counters + the count pass's dump slots
+    const size_t bsh = ((size_t)plan.nblk + 1) * sizeof(int);
     const int inter = (flavour & kRideInterleave) ? 1 : 0;
     const bool wide = (flavour & kRideWide) != 0, pt4 = (flavour & kRidePt4) != 0;
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdBin], st);

@@ -102,7 +102,10 @@ def test_no_kernel_spills_to_scratch(lib):
         sys.path.pop(0)
     from boxer_amd import _lib
     rows = kernel_resources.kernels(_lib.LIB_PATH)
-    assert len(rows) > 50, len(rows)
+    # every translation unit's code object (the library's fat binary holds one bundle per object: the window-staged
+    # kernels live in the third)
+    assert len(rows) > 150 and any("fwd_dense_kernel" in r[0] for r in rows) and \
+        any("softmax" in r[0] for r in rows), len(rows)
     spilling = [(name, scratch) for name, _v, _s, _lds, scratch in rows if int(scratch) != 0]
     assert not spilling, spilling
 

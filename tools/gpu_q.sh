@@ -1,12 +1,11 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -q -x -k "instance or inst or C3" 2>&1 | tail -4
-for w in C3 C3p; do for dt in fp32 bf16; do
-timeout 300 python bench.py --workload $w --dtype $dt --steps 2000 --warmup 100 --rotate 0 --no-cpu-baseline 2>&1 | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); r = d['roofline']
-        print('$w $dt', d['ms_per_step'], {k: v['avg_ms'] for k, v in r['kernels'].items()})
-"; done; done
+timeout 900 python -m pytest tests/test_gpu_dense.py tests/test_gpu_parity.py -m gpu -q -x -k "riders_match or rider_placement or match_oracle or algorithms or undersized or golden" 2>&1 | tail -4
+for i in 1 2; do
+VARIANT_DTYPES="bf16 fp32" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check
+done
+VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C2 --rotate 0 --no-check --opt 15=1
+VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C2p --rotate 0 --no-check
+VARIANT_DTYPES="bf16" bash tools/gpu_variants.sh --workload C5p --rotate 0 --no-check
+VARIANT_DTYPES="fp32" bash tools/gpu_variants.sh --workload C3 --rotate 0 --no-check

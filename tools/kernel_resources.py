@@ -14,13 +14,31 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def code_objects(path, tmp):
+    """The gfx950 code objects inside `path`: one per translation unit -- a linked library's .hip_fatbin section is
+    the concatenation of its objects' offload bundles (each starts with the bundler's magic string; the unbundler
+    itself only reads the first one)."""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)] or [0]
+    out = []
+    for i, a in enumerate(starts):
+        part = os.path.join(tmp, "fat%d.bin" % i)
+        with open(part, "wb") as fh:
+            fh.write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = os.path.join(tmp, "gfx950_%d.co" % i)
+        subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        out.append(co)
+    return out
+
+
 def kernels(path):
     tmp = tempfile.mkdtemp()
-    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.co")
-    subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path], check=True)
-    subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
-    notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+    notes = "".join(subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+                    for co in code_objects(path, tmp))
     rows = []
     for k in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
         g = lambda key: re.search(r"\.%s:\s+(\S+)" % key, k).group(1)
