@@ -173,7 +173,9 @@ def algorithmic_bytes(dims, kind, elem):
     GV = 4 * B * S * H * C
     fwd = Vr + W + O + M
     bwd = Vr + W + O + M + GV + W
-    per_kernel = {"fwd": fwd, "bwd_points": Vr + W + O + M + W, "bwd_accumulate": O + M + W + GV}
+    # the backward's two launches split the backward's compulsory bytes between them (they add up to `bwd`): what the
+    # accumulate launch re-reads of O / W -- through the bin records -- is traffic of OUR algorithm, not algorithmic
+    per_kernel = {"fwd": fwd, "bwd_points": Vr + W + O + M + W, "bwd_accumulate": GV}
     return fwd, bwd, per_kernel
 
 
@@ -479,18 +481,21 @@ def cpu_baseline(workload, budget_s=15.0):
                      "reference kernels (oracle/boxattn_oracle.c), %d iterations, %.3f s/iter, "
                      "%d OpenMP threads (one per image x head)" % (workload, batch, np_, iters,
                                                                    dt, cores)}
-    res["pytorch_fallback"] = pytorch_fallback_c1()
+    res["pytorch_fallback"] = pytorch_fallback("C1")
     return res
 
 
-def pytorch_fallback_c1(budget_s=8.0):
-    """BASELINE.json configs[0]: box attention as pure PyTorch on the CPU (grid_sample
-    formulation, fwd + autograd bwd), N=1, 1 level 64x64, 100 queries, 8 heads, 2x2 grid."""
+def pytorch_fallback(workload="C1", budget_s=8.0, iters=None):
+    """The north star's comparator: box attention as pure PyTorch on the CPU (grid_sample formulation, fwd + autograd
+    bwd; the reference's own oracle, tests/box_attn_test.py:9-42).  "C1" = BASELINE.json configs[0] (N=1, 1 level 64x64,
+    100 queries, 8 heads, 2x2 grid: bounded by `budget_s`); the headline shape (C2, B = 2) runs `iters` = 3 iterations on
+    all host cores."""
     from oracle import torch_fallback as tf
-    inp = make_inputs("C1", torch.float32, "cpu", family="model", batch=1, seed=0)
-    # (the op is tiny at this shape: beyond ~16 threads the intra-op fork/join dominates -- 256
-    # threads on the GPU box's host: 870 ms per iteration instead of a few ms)
-    cores = min(os.cpu_count() or 1, 16)
+    batch = 1 if workload == "C1" else BATCH
+    inp = make_inputs(workload, torch.float32, "cpu", family="model", batch=batch, seed=0)
+    # (C1 is tiny: beyond ~16 threads the intra-op fork/join dominates -- 256 threads on the GPU box's host: 870 ms
+    # per iteration instead of a few ms; the headline shape takes every core)
+    cores = min(os.cpu_count() or 1, 16) if workload == "C1" else (os.cpu_count() or 1)
     old_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
     v = inp["value"].clone().requires_grad_()
@@ -504,10 +509,11 @@ def pytorch_fallback_c1(budget_s=8.0):
         out.backward(inp["grad_out"])
 
     once()
-    t0 = time.perf_counter()
-    once()
-    first = time.perf_counter() - t0
-    iters = max(3, min(2000, int(budget_s / max(first, 1e-4))))
+    if iters is None:
+        t0 = time.perf_counter()
+        once()
+        first = time.perf_counter() - t0
+        iters = max(3, min(2000, int(budget_s / max(first, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(iters):
         once()
@@ -516,9 +522,10 @@ def pytorch_fallback_c1(budget_s=8.0):
     np_ = n_points(inp["dims"])
     return {"value": np_ / dt / 1e9, "unit": "Gsample-points/s", "cores": cores,
             "kind": "pure-PyTorch grid_sample formulation (oracle/torch_fallback.py)",
-            "sample": "C1 fp32: B=1, 1 level 64x64, 100 queries, 8 heads, C=32, 2x2 grid (%d "
+            "sample": "%s fp32: B=%d, levels %s, %d queries, 8 heads, C=32, %d points a level (%d sample "
                       "points), fwd + autograd bwd, %d iterations, %.3f ms/iter, torch threads=%d"
-                      % (np_, iters, dt * 1e3, cores)}
+                      % (workload, batch, "/".join("%dx%d" % hw for hw in WORKLOADS[workload][0]), inp["dims"]["Lq"],
+                         inp["dims"]["P"], np_, iters, dt * 1e3, cores)}
 
 
 # --------------------------------------------------------------------------------------
@@ -579,29 +586,15 @@ def spawn_ranks(n, cmd=None):
     return rc
 
 
-def rotated_leg(args, dtype, device, rank, np_rank):
-    """The same step over N input / upstream-gradient sets cycled from step to step (inputs
-    regenerated outside the timed region).  The headline leg replays ONE resident set -- inputs, outputs and records
-    of a C2 step are ~250 MB, about the size of the 256 MiB Infinity Cache -- so its traffic is partly served on-die;
-    here consecutive steps share nothing but the level tables."""
-    sets = [make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch, seed=1000 * (rank + 1) + i)
-            for i in range(args.rotate)]
-    steps = [make_step(x, args.entry) for x in sets]
-    n = len(steps)
-    k = [0]
-
-    def step():
-        k[0] += 1
-        return steps[k[0] % n]()
-    n_timed = max(n, min(args.steps, 1000) // n * n)
-    elapsed = run_timed(step, n_timed, min(max(args.warmup, n), 4 * n), torch.cuda.synchronize, None, device)
+def resident_leg(args, step, np_rank, device):
+    """The same step replaying ONE input set (the parity-gated one): inputs, outputs and bin records of a C2 step are
+    ~250 MB, about the size of the 256 MiB Infinity Cache, so part of its traffic is served on-die -- reported beside the
+    headline, which cycles N sets (inputs regenerated outside the timed region)."""
+    n_timed = max(1, min(args.steps, 1000))
+    elapsed = run_timed(step, n_timed, min(max(args.warmup, 8), 50), torch.cuda.synchronize, None, device)
     value, ms = throughput(elapsed, np_rank, 1, n_timed)
-    foot = sum(t.numel() * t.element_size() for x in sets for t in x.values() if isinstance(t, torch.Tensor))
-    return {"sets": n, "steps": n_timed, "ms_per_step": round(ms, 4), "value": round(value, 4),
-            "unit": "Gsample-points/s", "input_footprint_MB": round(foot / 1e6, 1),
-            "note": "inputs and upstream gradients of consecutive steps are different tensors (N sets generated "
-                    "before the timed region); outputs / gradients are allocated per step by torch's caching "
-                    "allocator as in the headline leg"}
+    return {"steps": n_timed, "ms_per_step": round(ms, 4), "value": round(value, 4), "unit": "Gsample-points/s",
+            "note": "one input set replayed (cache-resident): this rank alone, no barrier"}
 
 
 def main():
@@ -614,13 +607,15 @@ def main():
     ap.add_argument("--inputs", default="model", choices=["model", "test"])
     ap.add_argument("--batch", type=int, default=None,
                     help="images per GPU (the headline line uses the default: 2; C1: 1)")
-    ap.add_argument("--entry", default="ops", choices=["ops", "function", "reference"],
-                    help="what a step calls: the e2edet.ops boundary with the plan hand-over (default), the "
-                         "drop-in autograd Functions (.apply + .backward), or Functions in the reference's own shape "
-                         "on the compiled drop-in module (its four functions only)")
+    ap.add_argument("--entry", default="reference", choices=["ops", "function", "reference"],
+                    help="what a step calls: Functions in the reference's own shape on the compiled drop-in module -- "
+                         "its four functions only (default: the API the reference's model code calls), the e2edet.ops "
+                         "boundary of boxer_amd.ops with the plan hand-over, or boxer_amd's autograd Functions "
+                         "(.apply + .backward)")
     ap.add_argument("--rotate", type=int, default=8, metavar="N",
-                    help="second, cache-cold leg: N input / upstream-gradient sets (generated outside the timed "
-                         "region) cycled from step to step, reported as `rotated` (0: off)")
+                    help="the timed steps cycle N input / upstream-gradient sets generated outside the timed region "
+                         "(cache-cold: the headline); the one-set replay is reported beside it as `resident` "
+                         "(0 / 1: the headline replays one set)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a HIP graph and time replays (not the headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -660,18 +655,31 @@ def main():
     # every rank owns its own images (different seed): data-parallel shard, no exchange
     inp = make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch,
                       seed=rank)
-    step = make_step(inp, args.entry)
-    eager_step = step
+    step0 = make_step(inp, args.entry)
 
     # parity gate on the tensors of the step that is about to be timed (every rank its own)
     if not args.no_check:
-        failure = parity_gate(inp, step)
+        failure = parity_gate(inp, step0)
         if failure is not None:
             print("bench.py: parity gate FAILED on rank %d (%s %s %s): %s" % (
                 rank, args.workload, args.dtype, args.inputs, failure), file=sys.stderr, flush=True)
             sys.exit(3)
-    if args.graph:
-        step = graph_step(step)
+    # The HEADLINE cycles N input / upstream-gradient sets (generated here, outside the timed region: 544 MB at C2
+    # bf16): consecutive steps share nothing but the level tables, as consecutive layers / iterations of a training
+    # run do.  (One replayed set is cache-resident; it is timed too and reported as `resident`.)
+    n_sets = args.rotate if args.rotate > 1 else 1
+    sets = [inp] + [make_inputs(args.workload, dtype, device, family=args.inputs, batch=args.batch,
+                                seed=1000 * (rank + 1) + i) for i in range(1, n_sets)]
+    eager_fns = [step0] + [make_step(x, args.entry) for x in sets[1:]]
+    fns = [graph_step(f) for f in eager_fns] if args.graph else eager_fns
+    turn = [0]
+
+    def cycle(fs):
+        def step():
+            turn[0] += 1
+            return fs[turn[0] % len(fs)]()
+        return step
+    step, eager_step = cycle(fns), cycle(eager_fns)
 
     # Device pre-heat: the first ~100 steps after start-up run up to ~8 % slower than the steady state
     # (clock ramp, tools/gpu_ramp.py).  With a short --warmup the gap is filled here, outside
@@ -689,9 +697,7 @@ def main():
 
     np_rank = n_points(inp["dims"])
     value, ms_per_step = throughput(elapsed, np_rank, world, args.steps)
-    rotated = None
-    if args.rotate > 1 and world == 1:
-        rotated = rotated_leg(args, dtype, device, rank, np_rank)
+    resident = resident_leg(args, fns[0], np_rank, device) if n_sets > 1 else None
     per_rank = None
     if dist is not None:                   # per-rank spread (clock / power variance between GPUs)
         t0 = time.perf_counter()           # every rank alone, no barrier: its own rate
@@ -756,8 +762,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "launch": "hip-graph replay" if args.graph else "eager",
-            "entry": {"ops": "boxer_amd.ops.*_forward_train + *_backward(plan=...) (the e2edet.ops boundary with the "
-                             "plan hand-over the Functions use)",
+            "entry": {"ops": "boxer_amd.ops.*_forward_train + *_backward(plan=...) (the e2edet.ops boundary as "
+                             "boxer_amd's Functions call it)",
                       "function": "autograd Function .apply + .backward (the reference's call site, "
                                   "box_attention.py:234)",
                       "reference": "Functions in the reference's own shape (box_attention_func.py:10-64) on the "
@@ -776,12 +782,19 @@ def main():
                        "cell edge not compared)" % (PARITY_INFO.get("edge_points", -1), PARITY_INFO.get("points", -1))},
             "roofline": roofline,
         }
-        if rotated is not None:
-            line["rotated"] = rotated
+        line["inputs"] = ("%d input / upstream-gradient sets (%.0f MB) cycled from step to step: cache-cold" % (
+            n_sets, sum(t.numel() * t.element_size() for x in sets for t in x.values()
+                        if isinstance(t, torch.Tensor)) / 1e6)) if n_sets > 1 else "one input set replayed (cache-resident)"
+        if resident is not None:
+            line["resident"] = resident
         if per_rank is not None:
             line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
+            if inp["kind"] == "box" and not WORKLOADS[args.workload][3].startswith("box3d"):
+                # north_star's comparator at the shape of this line: the pure-PyTorch fallback on the host cores,
+                # 3 iterations -- a top-level key
+                line["pytorch_fallback_cpu"] = pytorch_fallback(args.workload, iters=3)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

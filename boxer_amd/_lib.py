@@ -42,11 +42,12 @@ _SIGNATURES = {
     "instattn_bwd": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp],
 }
 _WS_SIGNATURES = {
-    # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, plan, plan_bytes, stream
+    # plain backward args + shapes_host, lsi_host, workspace, workspace_bytes, plan, plan_bytes, state, state_bytes,
+    # hints, stream
     "boxattn_bwd_ws": [_vp] * 6 + _DIMS + [_vp] * 3 + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
-                                                       _i, _vp],
+                                                       _vp, ctypes.c_size_t, _i, _vp],
     "instattn_bwd_ws": [_vp] * 8 + _DIMS + [_vp] * 4 + [_vp, _vp, _vp, ctypes.c_size_t, _vp,
-                                                        ctypes.c_size_t, _i, _vp],
+                                                        ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _vp],
     # forward args + shapes_host, lsi_host, plan, plan_bytes, state, state_bytes, hints, int *plan_built, stream
     "boxattn_fwd_train": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                                       _i, _vp, _vp],
@@ -67,6 +68,7 @@ _GRIDATTN_SIGNATURES = {
 }
 NOT_ELIGIBLE = -2
 HINT_NOT_LOCAL = 1          # BOXATTN_HINT_NOT_LOCAL
+HINT_FRESH_STATE = 2        # BOXATTN_HINT_FRESH_STATE
 _ll = ctypes.c_longlong
 _POINTWISE_SIGNATURES = {
     "boxattn_softmax_fwd_f32": [_vp, _ll, _i, _vp, _vp],
@@ -93,7 +95,7 @@ EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
     "%s_%s" % (stem, suf) for stem in _SIGNATURES for suf in ("f32", "f64", "bf16")] + [
     "%s_%s" % (stem, suf) for stem in _WS_SIGNATURES for suf in ("f32", "bf16")]
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def hipcc_path():
@@ -221,7 +223,7 @@ def load():
     for name, args in list(_GRID_SIGNATURES.items()) + list(_POINTWISE_SIGNATURES.items()):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = _i
-    lib.boxattn_state_bytes.argtypes = [_i, _i]
+    lib.boxattn_state_bytes.argtypes = [_i] * 7 + [_vp, _vp]
     lib.boxattn_state_bytes.restype = ctypes.c_size_t
     for name in ("boxattn_bwd_workspace_bytes", "boxattn_plan_bytes"):
         getattr(lib, name).argtypes = [_i] * 8 + [_vp, _vp]

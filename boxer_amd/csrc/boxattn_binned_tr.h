@@ -26,6 +26,7 @@
 #include "boxattn_binplan.h"
 #include "boxattn_combine.h"
 #include "boxattn_scan_tail.h"
+#include "boxattn_binpass.h"      // redo_blocks (boxattn_spec.h)
 
 namespace boxattn {
 
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
     if (s >= n_slices || worker >= workers) return;
     const int b = s / H, h = s % H;
     const int lane = threadIdx.x;
-    if (worker < 0) {
-        zero_empty_blocks<ST, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+    if (worker < 0) {          // front rows of the grid: zero workers of a sparse map, or redo workers of the one-pass fill
+        if (zr.redo) redo_blocks<ST, C>(zr, plan, s, worker + plan.zero_workers, plan.zero_workers, S, H, Lq, grad_out, grad_value, lane);
+        else zero_empty_blocks<ST, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
         return;
     }
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, k-block
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int b = s / H, h = s % H;
     const int lane = threadIdx.x;
     if (worker < 0) {
-        zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        if (zr.redo) redo_blocks<float, C>(zr, plan, s, worker + plan.zero_workers, plan.zero_workers, S, H, Lq, grad_out, grad_value, lane);
+        else zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
         return;
     }
     const int col = lane & 31, kb = lane >> 5;
@@ -590,7 +593,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void bi
     const int b = s / H, h = s % H;
     const int lane = threadIdx.x;
     if (worker < 0) {
-        zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
+        if (zr.redo) redo_blocks<float, C>(zr, plan, s, worker + plan.zero_workers, plan.zero_workers, S, H, Lq, grad_out, grad_value, lane);
+        else zero_empty_blocks<float, C>(zr, plan.nblk, s, worker + plan.zero_workers, S, H, grad_value, lane);
         return;
     }
     const int col = lane & 31, kb = lane >> 5;     // operand row / column, record of the K = 2 step

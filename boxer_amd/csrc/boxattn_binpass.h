@@ -151,7 +151,8 @@ __device__ __forceinline__ void bin_pass_body(int *hist, BinLevel *s_lv, const f
 // ---------------------------------------------------------------------------------------
 // riders
 // ---------------------------------------------------------------------------------------
-enum { kRideWide = 1, kRideInterleave = 2, kRidePt4 = 4 };
+enum { kRideWide = 1, kRideInterleave = 2, kRidePt4 = 4,
+       kRideSpec = 8 };     // one-pass fill into guessed bin ranges (boxattn_spec.h); wide records, contiguous queries
 constexpr int kRideMaxBlocks = 3072;      // blocks per slice the riders' LDS histogram is built for (12 KB; beyond kScanThreads the
                                           // slice's last arriver scans in two passes over it: scan_blocks_big_body)
 constexpr int kRideLdsInts = kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeof(int)) + 4 * 4 + 2;
@@ -159,6 +160,13 @@ constexpr int kRideLdsInts = kRideMaxBlocks + 8 * (int)(sizeof(BinLevel) / sizeo
 // What a rider needs: the arguments of bin_kernel + the scan's outputs.  Passed BY VALUE all the way (a
 // kernel-argument struct handed on by reference was copied to scratch at the top of every wave of the host
 // kernel).
+// The caller's state of the one-pass fill (boxattn_spec.h): per slice the bins' ranges, their cursors, the redo list
+struct SpecRide {
+    int *cursor;                 // [slice][nblk]      next free record slot of every block (== cbase between calls)
+    int *cbase;                  // [slice][nblk + 1]  first slot of every block's range
+    int2 *redo;                  // [slice][1 + nblk]  {blocks that outgrew their range, 0}, then {block, geometry} each
+    unsigned long long *stats;   // [2] calls, blocks redone (only ever added to)
+};
 struct BinRide {
     const float *loc, *w_sp;
     int *part, *subtot, *offsets, *records;
@@ -168,8 +176,10 @@ struct BinRide {
     int *ctickets;           // fill: [slice][nblk] the accumulate launch's combine tickets, zeroed here (or null)
     BinPlan plan;
     int H, Lq, P, q_per_wg, n_wg;
+    unsigned nwg_magic;      // floor(2^32 / n_wg) (0xFFFFFFFF for 1): rider id -> (slice, bin workgroup) without a division
     int flavour;             // kRideWide | kRideInterleave | kRidePt4
     RideGrid grid;           // grid.n_riders == 0: no riders in this launch
+    SpecRide spec;           // flavour & kRideSpec
     unsigned long long *trace;   // builds with BOXATTN_RIDE_TRACE: 8 s_memrealtime stamps per rider (tools/gpu_ride_trace.py)
 };
 #ifndef BOXATTN_RIDE_TRACE
@@ -209,7 +219,9 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
     RIDE_STAMP(0);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
-    const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;
+    unsigned s_u, wg_u;
+    divmod_magic(id, (unsigned)r.n_wg, r.nwg_magic, s_u, wg_u);
+    const int s = (int)s_u, wg = (int)wg_u;
     const bool inter = (r.flavour & kRideInterleave) != 0;
     if (r.flavour & kRidePt4)
         bin_pass_body<THREADS, 8, 4, false, false, 4>(m.hist, m.lv, r.loc, r.w_sp, plan, r.H, r.Lq, r.P, r.q_per_wg,
@@ -244,16 +256,24 @@ __device__ __forceinline__ void bin_count_ride(const BinRide r, unsigned id, int
     RIDE_STAMP(4);
 }
 
+template <int THREADS> __device__ __forceinline__ void bin_fill_spec_ride(const BinRide r, unsigned id, int *lds);   // boxattn_spec.h
+
 // Fill rider `id` = (slice, bin workgroup); bin workgroup 0 of a slice also clears the slice's combine tickets.
 template <int THREADS>
 __device__ __forceinline__ void bin_fill_ride(const BinRide r, unsigned id, int *lds)
 {
     if (id >= r.grid.n_riders) return;
     if (BOXATTN_TUNE_RIDE_PRIO) __builtin_amdgcn_s_setprio(BOXATTN_TUNE_RIDE_PRIO);
+    if (r.flavour & kRideSpec) {        // one pass into guessed ranges, then the chain of the slice's last rider
+        bin_fill_spec_ride<THREADS>(r, id, lds);
+        return;
+    }
     RIDE_STAMP(5);
     const RideLds m(lds);
     const BinPlan plan = r.plan;
-    const int s = (int)id / r.n_wg, wg = (int)id % r.n_wg;
+    unsigned s_u, wg_u;
+    divmod_magic(id, (unsigned)r.n_wg, r.nwg_magic, s_u, wg_u);
+    const int s = (int)s_u, wg = (int)wg_u;
     const bool inter = (r.flavour & kRideInterleave) != 0;
     if (wg == 0 && r.ctickets)
         for (int k = threadIdx.x; k < plan.nblk; k += THREADS) r.ctickets[(size_t)s * plan.nblk + k] = 0;
@@ -271,3 +291,5 @@ __device__ __forceinline__ void bin_fill_ride(const BinRide r, unsigned id, int 
 }
 
 }  // namespace boxattn
+
+#include "boxattn_spec.h"

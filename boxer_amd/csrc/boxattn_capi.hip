@@ -38,7 +38,9 @@ enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels
        kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
        kOptRiders = 15,       // count / scan / fill / combine inside the forward, point-gradient and accumulate launches:
                               // 0 default (on; the combine inside the accumulate launch only for small problems), 1 off
-                              // (launches of their own), 2 on except the combine (its own launch), 3 on, combine inside
+                              // (launches of their own), 2 on except the combine (its own launch), 3 on, combine inside,
+                              // 4 on, but the two-pass binning of round 4 (count riders in the training forward, fill riders
+                              // against the exact scan) instead of the one-pass fill into guessed ranges (boxattn_spec.h)
        kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
        kOptAccF32 = 19,       // float32 box attention, C = 32, accumulate: 0 default (bf16 matrix cores on exact three-term
                               // splits), 1 VALU list walk (4-byte records), 2 v_mfma_f32_32x32x2_f32
@@ -68,10 +70,23 @@ inline bool opt_live(int k)
                                        // wave slots; 1024 thin ones cost all of them for as long (C2 bf16 step
                                        // 146 / 139 / 135 / 154 us with 1024 / 512 / 256 / 128 riders)
 #endif
-inline long long bin_wg_target()
+#ifndef BOXATTN_SPEC_Q_PER_RIDER
+#define BOXATTN_SPEC_Q_PER_RIDER 600   // ... of the one-pass fill (boxattn_spec.h) at encoder-sized problems: one rider per ~600
+                                       // (query, slice) pairs, 256 ... 768 of them.  Its riders are bound by latency (two
+                                       // barriers and an atomic round trip a step), not by instruction issue, so somewhat more,
+                                       // shorter riders than the two-pass fill wants.  C2 bf16 (213 k pairs), one box, resident /
+                                       // cache-cold inputs, us a step: 256 riders 126.3 / 140.2, 384: 122.5 / 132.9, 512: 119.8 /
+                                       // 135.0, 768: 119.3 / 135.0, 1024: 122.8 / 136.2 (two-pass, 256: 124.0 / 133.2); C2' (354 k):
+                                       // 512: 209.8 / 219.4, 1024: 218.5 / 225.1 (two-pass: 211.3 / 221.5) -- profiles/r06_onepass_ab.log
+#endif
+// one_pass: the shape's box-attention backward fills its bins in one pass (a property of the map, plan_layout)
+inline long long bin_wg_target(bool one_pass, long long queries)
 {
     const int v = (opt(kOptRideShift) >> 8) & 31;       // 64 v riders
-    return v > 0 ? 64ll * v : BOXATTN_BIN_WG_TARGET;
+    if (v > 0) return 64ll * v;
+    if (!one_pass || queries < 65536) return BOXATTN_BIN_WG_TARGET;
+    const long long r = (queries / BOXATTN_SPEC_Q_PER_RIDER + 32) / 64 * 64;
+    return std::min(768ll, std::max(256ll, r));
 }
 inline unsigned ride_shift(bool fill)
 {
@@ -537,6 +552,7 @@ inline BinRide make_ride(const float *loc, const float *w_sp, const Dims &d, con
     r.ctickets = fill && sl ? (int *)(sbuf + sl->ctickets) : nullptr;
     r.plan = plan;
     r.H = d.H; r.Lq = d.Lq; r.P = d.P; r.q_per_wg = pl.q_per_wg; r.n_wg = pl.n_wg;
+    r.nwg_magic = div_magic((unsigned)pl.n_wg);
     r.flavour = flavour;
     r.grid.n_riders = (unsigned)(pl.n_wg * d.B * d.H);
     r.grid.shift = ride_shift(fill);
@@ -757,12 +773,15 @@ int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, cons
 
 // A binned backward: [count -> scans, unless the training forward left a plan] -> point gradients with the
 // fill pass riding in their launch -> accumulate (chunked blocks summed by their last chunk).
+// spec: the caller's state of the one-pass fill (boxattn_spec.h) -- nullptr: two-pass binning; spec_warm: its ranges were
+// planned by an earlier call (else this call runs the two-pass passes and spec_layout_kernel plans them from its scan)
 template <typename ST, int G, bool INST>
 int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const PlanLayout &pl, char *pbuf, const ScratchLayout &sl,
                char *sbuf, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready,
-               hipStream_t st, const GridSrc *gs, const DensePlan *dp)
+               hipStream_t st, const GridSrc *gs, const DensePlan *dp, const SpecRide *spec = nullptr,
+               bool spec_warm = false, int *spec_tickets = nullptr)
 {
     const int ns = d.B * d.H;
     const AccKind acc = acc_kind<ST, INST>(d);
@@ -771,9 +790,20 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     float *partials = (float *)(sbuf + sl.partials);
     const int *n_items = (const int *)(pbuf + pl.n_items), *offsets = (const int *)(pbuf + pl.offsets);
     const int4 *items = (const int4 *)(pbuf + pl.items), *combos = (const int4 *)(pbuf + pl.combos);
-    if (!plan_ready) launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinCount | kBinScan);
+    const bool one_pass = spec && spec_warm;
+    if (!plan_ready && !one_pass) launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinCount | kBinScan);
     bool filled = false;
-    if (riders_ok(plan, pl)) {
+    if (one_pass) {
+        // point gradients + the fill riders' ONE pass over the locations into the ranges the state holds; the slice's
+        // last rider writes the work items (and the next call's ranges)
+        BinRide ride = make_ride(loc, w_sp, d, plan, pl, pbuf, &sl, sbuf, flavour | kRideSpec, true);
+        ride.spec = *spec;
+        ride.tickets = spec_tickets;
+        launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
+                                      grad_sp, grad_lv, st, gs, &ride, &filled, dp);
+        if (!filled)        // (the launched kernel carries no riders: the two-pass passes as launches, below)
+            launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinCount | kBinScan);
+    } else if (riders_ok(plan, pl)) {
         const BinRide ride = make_ride(loc, w_sp, d, plan, pl, pbuf, &sl, sbuf, flavour, true);
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
                                       grad_sp, grad_lv, st, gs, &ride, &filled, dp);
@@ -796,10 +826,18 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
     ChunkCombine cc{};
     if (!own_combine) cc = ChunkCombine{(int *)(sbuf + sl.ctickets), combos, plan.nblk, plan.pslot_cap};
     // (sparse maps: zero workers in front of the accumulate grid store the zeros of the blocks without records)
-    const ZeroRole zr{offsets, (const int2 *)(pbuf + pl.zgeo)};
-    int rc = launch_accumulate<ST, G, INST>(acc, grad_out, grad_mask, loc, w_sp, w_lv, d, plan, offsets, items,
+    ZeroRole zr{offsets, (const int2 *)(pbuf + pl.zgeo)};
+    BinPlan plan_acc = plan;
+    if (one_pass && filled) {       // the front rows of the grid: redo workers for the blocks that outgrew their range
+        zr = ZeroRole{nullptr, nullptr, spec->redo, loc, w_sp, d.P};
+        plan_acc.zero_workers = kSpecRedoWorkers;
+    }
+    int rc = launch_accumulate<ST, G, INST>(acc, grad_out, grad_mask, loc, w_sp, w_lv, d, plan_acc, offsets, items,
                                             n_items, records, grad_value, partials, cc, zr, st);
     if (rc) return rc;
+    if (spec && !(one_pass && filled))      // a cold state: the next call's ranges from this call's exact scan
+        hipLaunchKernelGGL(spec_layout_kernel<256>, dim3(ns), dim3(256), 0, st, plan, offsets, spec->cursor, spec->cbase,
+                           spec->redo);
     if (own_combine) {
         ScopedKernelTimer timer(g_prof.ev[kSlotBwdCombine], st);
         hipLaunchKernelGGL((combine_partials_kernel<ST, 4 * G>), dim3(64, ns), dim3(64), 0, st, combos,
@@ -816,7 +854,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
                   size_t workspace_bytes, const void *plan_buf, size_t plan_bytes, int hints, hipStream_t st,
-                  const GridSrc *gs = nullptr)
+                  const GridSrc *gs = nullptr, void *state = nullptr, size_t state_bytes = 0)
 {
     constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
     if (!d.valid()) return (int)hipErrorInvalidValue;
@@ -865,12 +903,31 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     DensePlan dense;
     const DensePlan *dp = !std::is_same<ST, double>::value && !INST && !(hints & BOXATTN_HINT_NOT_LOCAL) &&
                                   make_dense_plan(d, shapes_host, lsi_host, dense, (int)sizeof(ST)) ? &dense : nullptr;
+    // the one-pass fill (boxattn_spec.h): the caller's state holds the bins' ranges
+    SpecRide spec{};
+    const SpecRide *sp = nullptr;
+    bool spec_warm = false;
+    int *spec_tickets = nullptr;
+    if (!gs && !plan_ready && spec_ok<ST, INST>(d, plan, pl)) {
+        const StateLayout sy = state_layout(d, &plan);
+        const int chk = state_check(state, state_bytes, sy, d, shapes_host, st, (hints & BOXATTN_HINT_FRESH_STATE) != 0);
+        if (chk < 0) return (int)hipErrorInvalidValue;
+        if (chk > 0) {
+            char *sb = (char *)state;
+            spec = SpecRide{(int *)(sb + sy.cursor), (int *)(sb + sy.cbase), (int2 *)(sb + sy.redo),
+                            (unsigned long long *)(sb + sy.spec_stats)};
+            sp = &spec;
+            spec_warm = chk == 2;
+            spec_tickets = (int *)(sb + sy.tickets);
+            state_learned(state);        // (whichever way this call goes, it leaves the next call's ranges behind)
+        }
+    }
     switch (fast_group(d)) {
 #define BOXATTN_BINNED_CASE(GG)                                                                 \
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, pl, pbuf, sl, sbuf, grad_value, grad_loc, grad_sp, grad_lv, \
-                                      plan_ready, st, gs, dp);                                  \
+                                      plan_ready, st, gs, dp, sp, spec_warm, spec_tickets);     \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -891,16 +948,26 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
 {
     if (plan_built) *plan_built = 0;
     const bool allow_dense = !(hints & BOXATTN_HINT_NOT_LOCAL);
-    // the locality counters of the window-staged forward, then the riders' tickets
+    // the locality counters of the window-staged forward, then the riders' tickets, then the one-pass fill's ranges
     const size_t tbytes = (size_t)std::max(0, d.B) * (size_t)std::max(0, d.H) * kRideTickets * sizeof(int);
+    BinPlan plan;
+    const bool planned = d.valid() && make_plan(d, shapes_host, lsi_host, plan);
+    const StateLayout sy = state_layout(d, planned ? &plan : nullptr);
     // (a state buffer that is too small or misaligned is an error, not "no state": the caller would silently lose the
     // locality counters and pay a zero-fill launch in front of every forward)
-    if (state && (!aligned(state, 8) || state_bytes < kStatBytes + tbytes)) return (int)hipErrorInvalidValue;
+    if (state_check(state, state_bytes, sy, d, shapes_host, st, (hints & BOXATTN_HINT_FRESH_STATE) != 0) < 0)
+        return (int)hipErrorInvalidValue;
     const bool have_state = state != nullptr;
     unsigned long long *stats = have_state ? (unsigned long long *)state : nullptr;
-    BinPlan plan;
-    bool ok = (g_variant == 0 || g_variant == 3) && plan_buf && d.valid() &&
-              d.n_value() && d.n_qh() && make_plan(d, shapes_host, lsi_host, plan) &&
+    // The backward of this shape fills its bins in one pass, from ranges it keeps in the state buffer: nothing of the
+    // backward rides in the forward, and there is no plan to hand over (*plan_built stays 0)
+    if (have_state && planned && d.n_value() && d.n_qh() && (g_variant == 0 || g_variant == 3) &&
+        fast_ok<ST>(d, value, loc, out, INST ? (const void *)mask : (const void *)out, out) &&
+        spec_ok<ST, INST>(d, plan, plan_layout(d, plan)))
+        return launch_fwd<ST, INST>(value, shapes, lsi, loc, w_sp, w_lv, d, out, mask, st,
+                                    shapes_host, lsi_host, nullptr, nullptr, allow_dense, stats);
+    bool ok = (g_variant == 0 || g_variant == 3) && plan_buf && planned &&
+              d.n_value() && d.n_qh() &&
               aligned(plan_buf, 256) &&
               // what the backward will check and the forward can already see (its other operands,
               // grad_out / grad_value, are re-checked there; an ineligible backward ignores the plan)
@@ -924,7 +991,7 @@ int launch_fwd_train(const ST *value, const int64_t *shapes, const int64_t *lsi,
         // the forward kernel).
         BinRide ride = make_ride(loc, w_sp, d, plan, pl, pbuf, nullptr, nullptr, flavour, false);
         if (have_state) {
-            ride.tickets = (int *)((char *)state + kStatBytes);
+            ride.tickets = (int *)((char *)state + sy.tickets);
         } else {
             hipError_t e = zero_async(pbuf + pl.tickets, tbytes, st);
             if (e != hipSuccess) return (int)e;
@@ -999,9 +1066,13 @@ size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq
     return plan_layout(d, plan).total;
 }
 
-size_t boxattn_state_bytes(int B, int H)
+size_t boxattn_state_bytes(int B, int S, int H, int C, int L, int Lq, int P, const int64_t *shapes_host,
+                           const int64_t *lsi_host)
 {
-    return kStatBytes + (size_t)std::max(0, B) * (size_t)std::max(0, H) * kRideTickets * sizeof(int);
+    const Dims d = DIMS;
+    BinPlan plan;
+    const bool planned = d.valid() && make_plan(d, shapes_host, lsi_host, plan);
+    return state_layout(d, planned ? &plan : nullptr).total;
 }
 
 size_t boxattn_bwd_workspace_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
@@ -1020,23 +1091,24 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        const float *loc, const float *attn, const float *grad_out, int B, int S,
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
-                       void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes,
-                       int hints, void *stream)
+                       void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes, void *state,
+        size_t state_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                        grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                       workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
+                                       workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
 }
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, int hints, void *stream)
+                        const void *plan, size_t plan_bytes, void *state,
+        size_t state_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                         grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                        workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
+                                        workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
 }
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
@@ -1044,11 +1116,12 @@ int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, int hints, void *stream)
+                        const void *plan, size_t plan_bytes, void *state,
+        size_t state_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                       grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
+                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
 }
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
@@ -1056,11 +1129,12 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         const void *plan, size_t plan_bytes, int hints, void *stream)
+                         const void *plan, size_t plan_bytes, void *state,
+        size_t state_bytes, int hints, void *stream)
 {
     return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                        grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_);
+                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
 }
 
 
@@ -1072,8 +1146,8 @@ const char *boxattn_build_info(void)
            " | kernels: generic{f32,f64,bf16}, gather{f32 4ch/lane, bf16 8ch/lane} C={16,32,64}, "
            "window-staged encoder forward + point gradients{bf16 on MFMA 4x4x4, f32 on VALU}, "
            "binned-bwd{bf16 on MFMA 32x32x16, f32 on the same MFMA over exact three-term bf16 splits} "
-           "with count / scan / fill / combine riding in the forward, point-gradient and accumulate launches, "
-           "box-grid{f32} | abi 7";
+           "with fill / combine riding in the point-gradient and accumulate launches, "
+           "one-pass fill into guessed bin ranges (caller-owned state), box-grid{f32} | abi 8";
 }
 
 int boxattn_profile_begin(void)

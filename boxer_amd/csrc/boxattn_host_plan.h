@@ -164,7 +164,11 @@ inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
     PlanLayout w;
     // ~2048 workgroups of 256 threads' worth of bin workgroups
     // ... and at most kScanSub * kScanWgPerSub per slice (the scan's two levels)
-    const long long wg_target = bin_wg_target();
+    // (a shape whose box-attention backward takes the one-pass fill gets more, shorter riders -- whatever the storage
+    // type or operator of THIS call: the layout is a function of the dimensions and the switches alone)
+    const int o15 = opt(kOptRiders);
+    const bool one_pass = (o15 == 0 || o15 == 2 || o15 == 3) && p.nblk <= kSpecMaxBlocks && p.min_items == 1;
+    const long long wg_target = bin_wg_target(one_pass, (long long)d.Lq * (long long)ns);
     w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
     w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
                                           (kScanSub * kScanWgPerSub));
@@ -214,6 +218,80 @@ inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
 {
     return opt(kOptRiders) != 1 && plan.nblk <= kRideMaxBlocks && plan.min_items == 1 &&
            w.n_wg <= kScanSub * kScanWgPerSub;
+}
+
+// ------------------------------------------------- the one-pass fill's state (boxattn_spec.h)
+// Does the backward of this call fill its bins in one pass, into ranges kept in the caller's state buffer?  Box
+// attention with 16-byte records (the matrix-core accumulates), maps the riders' two LDS arrays hold.
+template <typename ST, bool INST> inline bool spec_ok(const Dims &d, const BinPlan &plan, const PlanLayout &pl)
+{
+    if (INST || std::is_same<ST, double>::value) return false;
+    const int o = opt(kOptRiders);
+    return (o == 0 || o == 2 || o == 3) && acc_kind<ST, INST>(d) != kAccValu && riders_ok(plan, pl) &&
+           plan.nblk <= kSpecMaxBlocks && (long long)d.Lq * d.P < (1 << 24) && plan.rec_cap < (1 << 28) &&
+           d.n_qh() * (size_t)d.L * (size_t)d.P < ((size_t)1 << 29);
+}
+
+// The state buffer: [locality counters 1 KiB][one-pass counters 64 B][tickets][cursor][cbase][redo] -- the last three only
+// for shapes the binned backward plans (every such shape: the size does not depend on the storage type or the switches).
+struct StateLayout { size_t spec_stats, tickets, cursor, cbase, redo, total; };
+inline StateLayout state_layout(const Dims &d, const BinPlan *plan)
+{
+    const size_t ns = (size_t)std::max(0, d.B) * (size_t)std::max(0, d.H);
+    StateLayout w;
+    size_t o = kStatBytes;
+    w.spec_stats = o; o += 64;
+    w.tickets = o;    o += align_up(ns * kRideTickets * sizeof(int));
+    w.cursor = w.cbase = w.redo = o;
+    if (plan && plan->nblk <= kSpecMaxBlocks) {
+        w.cursor = o; o += align_up(ns * (size_t)plan->nblk * sizeof(int));
+        w.cbase = o;  o += align_up(ns * ((size_t)plan->nblk + 1) * sizeof(int));
+        w.redo = o;   o += align_up(ns * ((size_t)plan->nblk + 1) * sizeof(int2));
+    }
+    w.total = o;
+    return w;
+}
+
+// What the library remembers (host side) of the state buffers it has seen: the shape a buffer serves and whether a call
+// has planned its ranges.  A buffer is the caller's -- zeroed once, one per (stream, dimensions, level shapes) -- and a
+// zeroed buffer is a valid state (every range empty), so nothing here decides RESULTS: an unknown or forgotten buffer is
+// "cold" (the call runs the two-pass passes and plans the ranges), and a buffer that turns up with another shape is
+// zeroed first (its tickets and ranges mean nothing to this shape).
+struct StateShadow { Dims d; unsigned long long geo; bool learned; };
+std::mutex g_state_mu;
+std::map<const void *, StateShadow> g_state_shadow;
+inline bool same_dims(const Dims &a, const Dims &b)
+{
+    return a.B == b.B && a.S == b.S && a.H == b.H && a.C == b.C && a.L == b.L && a.Lq == b.Lq && a.P == b.P;
+}
+// -> -1 unusable (misaligned / too small), 0 no state, 1 cold, 2 its ranges are planned
+// fresh (BOXATTN_HINT_FRESH_STATE): the caller has zeroed the buffer since its last call -- a new buffer, possibly at an
+// address another one had: whatever is remembered of the address is dropped
+inline int state_check(void *state, size_t bytes, const StateLayout &sy, const Dims &d, const int64_t *sh, hipStream_t st,
+                       bool fresh = false)
+{
+    if (!state) return 0;
+    if (!aligned(state, 8) || bytes < sy.total) return -1;
+    unsigned long long geo = 1469598103934665603ull;                    // FNV-1a over the level shapes
+    for (int i = 0; sh && i < 2 * d.L; ++i) geo = (geo ^ (unsigned long long)sh[i]) * 1099511628211ull;
+    std::lock_guard<std::mutex> g(g_state_mu);
+    if (fresh) g_state_shadow.erase(state);
+    const auto it = g_state_shadow.find(state);
+    if (it == g_state_shadow.end()) {
+        if (g_state_shadow.size() >= 4096) g_state_shadow.clear();
+        g_state_shadow[state] = StateShadow{d, geo, false};
+        return 1;
+    }
+    if (same_dims(it->second.d, d) && it->second.geo == geo) return it->second.learned ? 2 : 1;
+    if (zero_async((char *)state + kStatBytes, bytes - kStatBytes, st) != hipSuccess) return -1;
+    it->second = StateShadow{d, geo, false};
+    return 1;
+}
+inline void state_learned(const void *state)
+{
+    std::lock_guard<std::mutex> g(g_state_mu);
+    const auto it = g_state_shadow.find(state);
+    if (it != g_state_shadow.end()) it->second.learned = true;
 }
 
 // ------------------------------------------------- window-staged encoder kernels (boxattn_dense.h)

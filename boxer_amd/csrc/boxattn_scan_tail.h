@@ -285,6 +285,10 @@ constexpr int kZeroPer = 32;     // blocks per zero worker (BinPlan::zero_worker
 struct ZeroRole {
     const int *offsets;          // [slice][nblk + 1], written by the scan
     const int2 *geo;             // [nblk] {first pixel of the block (index into S), W | bh - 1 << 16 | bw - 1 << 18}: zero_geo_kernel (boxattn_binned.h)
+    // the same front rows of the accumulate grid as REDO workers of the one-pass fill (boxattn_spec.h; redo != nullptr, offsets == nullptr):
+    const int2 *redo;            // [slice][1 + nblk] {count, 0}, {block, geometry}...: blocks that outgrew their guessed range
+    const float *loc, *w_sp;     // the call's sampling locations / attention weights
+    int P;
 };
 // (The block geometry comes from a table, not from the plan in the kernel arguments: selecting a level's
 // entry there costs the accumulate kernels ~40 scalar registers at their top, which they do not have --

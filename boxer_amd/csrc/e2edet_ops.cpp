@@ -16,6 +16,7 @@
 
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -148,7 +149,20 @@ struct HostTables {
 };
 
 typedef std::pair<int, void *> StreamKey;               // (device index, stream handle)
-std::map<StreamKey, at::Tensor> g_workspace, g_state;
+std::map<StreamKey, at::Tensor> g_workspace;
+// (device, stream, B, S, H, C, L, Lq, P, storage type, hash of the level shapes): ABI 8 keeps the record ranges of the
+// backward's one-pass fill in the state buffer -- one buffer per geometry
+typedef std::tuple<int, void *, int, int, int, int, int, int, int, int, uint64_t> StateKey;
+struct StateEntry { at::Tensor buf; bool fresh; };      // fresh: zeroed, not yet handed to the library (BOXATTN_HINT_FRESH_STATE)
+std::map<StateKey, StateEntry> g_state;
+constexpr size_t kStateCap = 1024;
+
+// a tensor created while the stream captures a graph lives in the graph's private pool: it serves the call, but must
+// not outlive the graph in a process-wide table (boxer_amd/ops.py has the same guard)
+bool capturing()
+{
+    return c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
+}
 
 // the backward's scratch of this stream (contents only live inside one call; calls on a stream never overlap)
 at::Tensor workspace(const at::Tensor &value, const Dims &d, const HostTables &h, void *stream)
@@ -157,26 +171,41 @@ at::Tensor workspace(const at::Tensor &value, const Dims &d, const HostTables &h
         boxattn_bwd_workspace_bytes(value.scalar_type() == at::kBFloat16, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
                                     h.sh(), h.ls()), 256);
     const StreamKey key(value.get_device(), stream);
+    const bool keep = !capturing();
     std::lock_guard<std::mutex> g(g_mu);
-    at::Tensor &ws = g_workspace[key];
-    if (!ws.defined() || (size_t)ws.numel() < bytes)
-        ws = at::empty({(int64_t)bytes}, value.options().dtype(at::kByte));
+    const auto it = g_workspace.find(key);
+    if (it != g_workspace.end() && (size_t)it->second.numel() >= bytes) return it->second;
+    at::Tensor ws = at::empty({(int64_t)bytes}, value.options().dtype(at::kByte));
+    if (keep) g_workspace[key] = ws;
     return ws;
 }
-// the library's state buffer of this stream: zeroed once, every call leaves its tickets zero
-at::Tensor state(const at::Tensor &value, const Dims &d, void *stream)
+// the library's state buffer of this (stream, geometry): zeroed once; every call leaves its tickets zero and the
+// record ranges of the next backward's one-pass fill
+at::Tensor state(const at::Tensor &value, const Dims &d, const HostTables &h, void *stream, int *hints)
 {
-    const size_t bytes = boxattn_state_bytes(d.B, d.H);
-    const StreamKey key(value.get_device(), stream);
+    const size_t bytes = boxattn_state_bytes(d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, h.sh(), h.ls());
+    uint64_t geo = 1469598103934665603ull;
+    for (int i = 0; i < 2 * d.L; ++i) geo = (geo ^ (uint64_t)h.sh()[i]) * 1099511628211ull;
+    const StateKey key(value.get_device(), stream, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, (int)value.scalar_type(), geo);
+    const bool keep = !capturing();
     std::lock_guard<std::mutex> g(g_mu);
-    at::Tensor &st = g_state[key];
-    if (!st.defined() || (size_t)st.numel() < bytes)
-        st = at::zeros({(int64_t)bytes}, value.options().dtype(at::kByte));
+    const auto it = g_state.find(key);
+    if (it != g_state.end() && (size_t)it->second.buf.numel() >= bytes) {
+        if (it->second.fresh) *hints |= BOXATTN_HINT_FRESH_STATE;
+        it->second.fresh = false;
+        return it->second.buf;
+    }
+    at::Tensor st = at::zeros({(int64_t)bytes}, value.options().dtype(at::kByte));
+    *hints |= BOXATTN_HINT_FRESH_STATE;
+    if (keep) {
+        if (g_state.size() >= kStateCap) g_state.clear();
+        g_state[key] = StateEntry{st, false};
+    }
     return st;
 }
 
 // ---- parked plans
-typedef std::tuple<int, void *, int, int, int, int, int, int, int, int, const void *, uint32_t, const void *, uint32_t,
+typedef std::tuple<int, void *, int, int, int, int, int, int, int, int, int, const void *, uint32_t, const void *, uint32_t,
                    const void *, uint32_t> PlanKey;
 struct Parked {
     PlanKey key;
@@ -189,12 +218,15 @@ constexpr size_t kParkCap = 32;
 PlanKey plan_key(const at::Tensor &value, void *stream, const Dims &d, const at::Tensor &loc, const at::Tensor &w0,
                  const at::Tensor *w1)
 {
+    // (the storage type is part of the key: at 16 / 64 channels per head a bfloat16 plan bins contiguous query ranges,
+    // a float32 one interleaved ones)
     return PlanKey(value.get_device(), stream, d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, boxattn_options_epoch(),
-                   loc.data_ptr(), version_of(loc), w0.data_ptr(), version_of(w0), w1 ? w1->data_ptr() : nullptr,
+                   (int)value.scalar_type(), loc.data_ptr(), version_of(loc), w0.data_ptr(), version_of(w0), w1 ? w1->data_ptr() : nullptr,
                    w1 ? version_of(*w1) : 0u);
 }
 void park(PlanKey key, at::Tensor plan, std::vector<at::Tensor> keep)
 {
+    if (capturing()) return;       // (the plan tensor belongs to the graph's pool; the backward plans for itself)
     std::lock_guard<std::mutex> g(g_mu);
     for (auto it = g_parked.begin(); it != g_parked.end();)
         it = it->key == key ? g_parked.erase(it) : it + 1;
@@ -251,18 +283,19 @@ at::Tensor box_attn_forward(const at::Tensor &value, const at::Tensor &spatial_s
         at::Tensor plan;
         if (wants_plan({&value, &sampling_loc, &attn_weight})) plan = plan_buffer(value, d, h);
         if (plan.defined()) {          // a backward will follow: the forward's launch prepares its plan
-            at::Tensor state_buf = state(value, d, st);
+            int hints = 0;
+            at::Tensor state_buf = state(value, d, h, st, &hints);
             int built = 0;
             if (value.scalar_type() == at::kFloat)
                 rc = boxattn_fwd_train_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
                                            attn_weight.data_ptr<float>(), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
                                            out.data_ptr<float>(), h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(),
-                                           state_buf.data_ptr(), (size_t)state_buf.numel(), 0, &built, st);
+                                           state_buf.data_ptr(), (size_t)state_buf.numel(), hints, &built, st);
             else
                 rc = boxattn_fwd_train_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                                             attn_weight.data_ptr<float>(), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, bf(out),
                                             h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(), state_buf.data_ptr(),
-                                            (size_t)state_buf.numel(), 0, &built, st);
+                                            (size_t)state_buf.numel(), hints, &built, st);
             if (rc == 0 && built)
                 park(plan_key(value, st, d, sampling_loc, attn_weight, nullptr), plan, {sampling_loc, attn_weight});
         } else if (value.scalar_type() == at::kFloat)
@@ -308,6 +341,8 @@ std::vector<at::Tensor> box_attn_backward(const at::Tensor &value, const at::Ten
     } else {
         const HostTables h(spatial_shapes, level_start_index);
         at::Tensor ws = workspace(value, d, h, st);
+        int hints = 0;
+            at::Tensor state_buf = state(value, d, h, st, &hints);
         const at::Tensor plan = take_parked(plan_key(value, st, d, sampling_loc, attn_weight, nullptr));
         const void *pp = plan.defined() ? plan.data_ptr() : nullptr;
         const size_t pn = plan.defined() ? (size_t)plan.numel() : 0;
@@ -316,13 +351,14 @@ std::vector<at::Tensor> box_attn_backward(const at::Tensor &value, const at::Ten
                                     attn_weight.data_ptr<float>(), grad_output.data_ptr<float>(),
                                     d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(),
                                     grad_loc.data_ptr<float>(), grad_attn.data_ptr<float>(), h.sh(),
-                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn, 0, st);
+                                    h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn, state_buf.data_ptr(),
+                                    (size_t)state_buf.numel(), hints, st);
         else
             rc = boxattn_bwd_ws_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                                      attn_weight.data_ptr<float>(), bf(grad_output), d.B, d.S, d.H,
                                      d.C, d.L, d.Lq, d.P, bf(grad_value), grad_loc.data_ptr<float>(),
                                      grad_attn.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                                     (size_t)ws.numel(), pp, pn, 0, st);
+                                     (size_t)ws.numel(), pp, pn, state_buf.data_ptr(), (size_t)state_buf.numel(), hints, st);
     }
     check_rc(rc, "boxattn_bwd");
     return {grad_value, grad_loc, grad_attn};
@@ -351,20 +387,21 @@ std::vector<at::Tensor> instance_attn_forward(const at::Tensor &value,
         const HostTables h(spatial_shapes, level_start_index);
         plan = plan_buffer(value, d, h);
         if (plan.defined()) {
-            at::Tensor state_buf = state(value, d, st);
+            int hints = 0;
+            at::Tensor state_buf = state(value, d, h, st, &hints);
             int built = 0;
             if (value.scalar_type() == at::kFloat)
                 rc = instattn_fwd_train_f32(value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
                                             spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
                                             d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, out.data_ptr<float>(),
                                             mask.data_ptr<float>(), h.sh(), h.ls(), plan.data_ptr(), (size_t)plan.numel(),
-                                            state_buf.data_ptr(), (size_t)state_buf.numel(), 0, &built, st);
+                                            state_buf.data_ptr(), (size_t)state_buf.numel(), hints, &built, st);
             else
                 rc = instattn_fwd_train_bf16(bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                                              spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
                                              d.B, d.S, d.H, d.C, d.L, d.Lq, d.P, bf(out), bf(mask), h.sh(), h.ls(),
                                              plan.data_ptr(), (size_t)plan.numel(), state_buf.data_ptr(),
-                                             (size_t)state_buf.numel(), 0, &built, st);
+                                             (size_t)state_buf.numel(), hints, &built, st);
             if (rc == 0 && built)
                 park(plan_key(value, st, d, sampling_loc, spatial_attn_weight, &level_attn_weight), plan,
                      {sampling_loc, spatial_attn_weight, level_attn_weight});
@@ -427,6 +464,8 @@ std::vector<at::Tensor> instance_attn_backward(
     } else {
         const HostTables h(spatial_shapes, level_start_index);
         at::Tensor ws = workspace(value, d, h, st);
+        int hints = 0;
+            at::Tensor state_buf = state(value, d, h, st, &hints);
         const at::Tensor plan =
             take_parked(plan_key(value, st, d, sampling_loc, spatial_attn_weight, &level_attn_weight));
         const void *pp = plan.defined() ? plan.data_ptr() : nullptr;
@@ -438,14 +477,15 @@ std::vector<at::Tensor> instance_attn_backward(
                 grad_output.data_ptr<float>(), grad_mask_output.data_ptr<float>(), d.B, d.S, d.H,
                 d.C, d.L, d.Lq, d.P, grad_value.data_ptr<float>(), grad_loc.data_ptr<float>(),
                 grad_sw.data_ptr<float>(), grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(),
-                (size_t)ws.numel(), pp, pn, 0, st);
+                (size_t)ws.numel(), pp, pn, state_buf.data_ptr(), (size_t)state_buf.numel(), hints, st);
         else
             rc = instattn_bwd_ws_bf16(
                 bf(value), sh, ls, sampling_loc.data_ptr<float>(),
                 spatial_attn_weight.data_ptr<float>(), level_attn_weight.data_ptr<float>(),
                 bf(grad_output), bf(grad_mask_output), d.B, d.S, d.H, d.C, d.L, d.Lq, d.P,
                 bf(grad_value), grad_loc.data_ptr<float>(), grad_sw.data_ptr<float>(),
-                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn, 0, st);
+                grad_lw.data_ptr<float>(), h.sh(), h.ls(), ws.data_ptr(), (size_t)ws.numel(), pp, pn,
+                state_buf.data_ptr(), (size_t)state_buf.numel(), hints, st);
     }
     check_rc(rc, "instattn_bwd");
     return {grad_value, grad_loc, grad_sw, grad_lw};

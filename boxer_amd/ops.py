@@ -101,11 +101,12 @@ class BackwardPlan:
         self.keep = None                                       # parked plans: the tensors the key names (see _park)
 
 
-def _plan_key(dims, loc, weights):
+def _plan_key(dims, loc, weights, dtype=None):
     # (the library's option switches -- records per item, riders, accumulate flavour, variant -- change the plan's
-    # layout: a plan built under other settings is not this call's plan)
-    return (tuple(dims), loc.device.index, _lib.options_epoch()) + tuple((t.data_ptr(), t._version)
-                                                                         for t in (loc,) + tuple(weights))
+    # layout: a plan built under other settings is not this call's plan; so does the storage type: at 16 / 64 channels
+    # per head bfloat16 bins contiguous query ranges and float32 interleaved ones)
+    return (tuple(dims), loc.device.index, _lib.options_epoch(), dtype) + tuple((t.data_ptr(), t._version)
+                                                                                for t in (loc,) + tuple(weights))
 
 
 class _NoGuard:
@@ -165,6 +166,7 @@ def _state_buffer(key, device, nbytes):
     buf = _STATE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        buf._boxattn_fresh = True        # (its first call says so: BOXATTN_HINT_FRESH_STATE)
         # (a tensor first created while the stream captures a graph lives in the graph's private pool: it serves
         # this call -- the graph keeps it alive -- but must not outlive the graph in this table)
         if not torch.cuda.is_current_stream_capturing():
@@ -194,6 +196,7 @@ class _Locality:
         self.ratio = None            # the miss ratio the current choice is based on
         self.since_read = 0
         self.reads = 0
+        self.last_hints = 0          # of the last training forward (a backward that gets no plan follows them)
 
     READ_EVERY = 16                  # staged calls between two reads of the counters
 
@@ -245,8 +248,23 @@ class _Locality:
 _LOCALITY = {}       # (device index, stream handle, dims) -> _Locality
 
 
-def _shape_key(value, stream, dims):
-    return (value.device.index, stream, tuple(dims), value.dtype)
+def _shape_key(value, stream, dims, sh, ls):
+    # one state buffer per (device, stream, dimensions, storage type, level shapes): ABI 8 keeps the record ranges of the
+    # backward's one-pass fill in it, which belong to ONE geometry
+    return (value.device.index, stream, tuple(dims), value.dtype, sh.tobytes(), ls.tobytes())
+
+
+def _fresh_hint(state):
+    return _lib.HINT_FRESH_STATE if getattr(state, "_boxattn_fresh", False) else 0
+
+
+def _state_for(lib, value, dims, sh, ls, stream):
+    key = _shape_key(value, stream, dims, sh, ls)
+    skey = ("state",) + key[2:]
+    nbytes = _SIZES.get(skey)
+    if nbytes is None:
+        nbytes = _bounded(_SIZES)[skey] = int(lib.boxattn_state_bytes(*dims, sh.ctypes.data, ls.ctypes.data))
+    return key, _state_buffer(key, value.device, nbytes)
 
 
 def _locality(key):
@@ -267,21 +285,26 @@ def _forward_train(name, value, shapes, lsi, loc, weights, dims, args):
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
     with _device_guard(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
-        key = _shape_key(value, stream, dims)
-        state = _state_buffer(key, value.device, lib.boxattn_state_bytes(dims[0], dims[2]))
+        key, state = _state_for(lib, value, dims, sh, ls, stream)
         adapt = _locality(key)
         hints = adapt.hints()
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, buf.data_ptr() if buf is not None else 0,
-                buf.numel() if buf is not None else 0, state.data_ptr(), state.numel(), hints,
+                buf.numel() if buf is not None else 0, state.data_ptr(), state.numel(), hints | _fresh_hint(state),
                 ctypes.addressof(built), stream)
         if rc == 0:
+            state._boxattn_fresh = False
             adapt.after_call(state, hints)
+            adapt.last_hints = hints
     if rc != 0:
         _STATE.pop(key, None)                                # (its tickets may not be zero any more)
         _LOCALITY.pop(key, None)
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
-    return BackwardPlan(buf, _plan_key(dims, loc, weights), hints) if built.value else None
+    if built.value:
+        return BackwardPlan(buf, _plan_key(dims, loc, weights, value.dtype), hints)
+    # no plan to hand over: the backward of this shape fills its bins in one pass from the ranges in the state buffer
+    # (ABI 8), or plans for itself.  The object still carries the hints the forward ran with.
+    return BackwardPlan(None, _plan_key(dims, loc, weights, value.dtype), hints)
 
 
 def workspace_bytes(value, shapes, lsi, dims):
@@ -373,7 +396,7 @@ def _wants_plan(*tensors):
 
 
 def _park(value, plan, keep):
-    if plan is None:
+    if plan is None or plan.buf is None:
         return
     # The key names the location / weight tensors by address and version.  A parked plan HOLDS them: as long as it is
     # parked their memory cannot be freed and handed to another tensor, so a backward that presents the same
@@ -390,7 +413,7 @@ def _parked(value, dims, loc, weights):
     if not _PARKED:
         return None
     stream = torch.cuda.current_stream(value.device).cuda_stream
-    plan = _PARKED.pop((value.device.index, stream) + _plan_key(dims, loc, weights), None)
+    plan = _PARKED.pop((value.device.index, stream) + _plan_key(dims, loc, weights, value.dtype), None)
     if plan is not None:
         plan.keep = None
     return plan
@@ -399,17 +422,22 @@ def _parked(value, dims, loc, weights):
 def _backward_with_workspace(name, value, shapes, lsi, loc, weights, dims, args, plan=None):
     """Run the *_bwd_ws_* entry point (float32 / bfloat16): host level tables + scratch (+ plan)."""
     lib = _lib.load()
-    ready = plan is not None and plan.key == _plan_key(dims, loc, weights)
+    ready = plan is not None and plan.buf is not None and plan.key == _plan_key(dims, loc, weights, value.dtype)
     fn = getattr(lib, "%s_%s" % (name, _SUFFIX[value.dtype]))
     with _device_guard(value.device):
         stream = torch.cuda.current_stream(value.device).cuda_stream
         ws, sh, ls = _workspace(lib.boxattn_bwd_workspace_bytes, value, shapes, lsi, dims, stream)
+        # the state buffer of this (stream, shape): the record ranges of the one-pass fill live in it from call to call
+        key, state = _state_for(lib, value, dims, sh, ls, stream)
+        hints = plan.hints if plan is not None else (_LOCALITY[key].last_hints if key in _LOCALITY else 0)
         rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args],
                 sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(),
                 plan.buf.data_ptr() if ready else 0, plan.buf.numel() if ready else 0,
-                plan.hints if plan is not None else 0, stream)
+                state.data_ptr(), state.numel(), hints | _fresh_hint(state), stream)
     if rc != 0:
+        _STATE.pop(key, None)
         raise RuntimeError("%s_%s failed with hipError %d" % (name, _SUFFIX[value.dtype], rc))
+    state._boxattn_fresh = False
 
 
 def _call(name, value, *args):

@@ -47,7 +47,7 @@ extern "C" {
 #endif
 
 /* ABI version of this header; bumped on any signature change. */
-#define BOXATTN_ABI_VERSION 7
+#define BOXATTN_ABI_VERSION 8
 int boxattn_abi_version(void);
 
 /* Static description of the build ("gfx950", compiler, kernel variants); never NULL. */
@@ -139,6 +139,14 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
  *       buffer a *_fwd_train_* call filled (*plan_built == 1) for the SAME sampling locations,
  *       dimensions and option settings; it is only read.
  *   hints : 0, or BOXATTN_HINT_* bits (see *_fwd_train_*); speed only, never results.
+ *   state / state_bytes : NULL / 0, or the caller's state buffer of this (stream, dimensions, level shapes) -- see
+ *       *_fwd_train_* below.  With it, box attention whose accumulate runs on the matrix cores (bf16 storage at 16 /
+ *       32 / 64 channels per head, float32 at 32) on maps of up to 1 535 blocks of 8x4 pixels per (image, head) fills
+ *       its bins in ONE pass: the state keeps, per block, the record range the previous call planned
+ *       from its own counts; the fill riders claim slots in those ranges with one returned atomic per block and step;
+ *       a block that outgrows its range is recomputed from the sampling locations by a redo worker of the accumulate
+ *       launch; every call re-plans the ranges for the next one.  Results never depend on what the state holds; the
+ *       first call on a zeroed (or foreign-shaped) state runs the two-pass passes.  Such a call takes no plan.
  * If the shape is not eligible or the workspace is too small, the call falls back to the
  * atomic kernels of the plain entry points (for _bf16 the workspace must then still hold
  * B*S*H*C floats); a plan the backward cannot use (operands the fast paths reject) is ignored.
@@ -154,27 +162,30 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
                        int H, int C, int L, int Lq, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, const int64_t *shapes_host, const int64_t *lsi_host,
                        void *workspace, size_t workspace_bytes, const void *plan, size_t plan_bytes,
-                       int hints, void *stream);
+                       void *state, size_t state_bytes, int hints, void *stream);
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
                         int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
                         float *grad_loc, float *grad_attn, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, int hints, void *stream);
+                        const void *plan, size_t plan_bytes, void *state, size_t state_bytes, int hints,
+                        void *stream);
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
                         const float *grad_out, const float *grad_mask, int B, int S, int H, int C,
                         int L, int Lq, int P, float *grad_value, float *grad_loc,
                         float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                         const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                        const void *plan, size_t plan_bytes, int hints, void *stream);
+                        const void *plan, size_t plan_bytes, void *state, size_t state_bytes, int hints,
+                        void *stream);
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
                          const uint16_t *grad_out, const uint16_t *grad_mask, int B, int S, int H,
                          int C, int L, int Lq, int P, uint16_t *grad_value, float *grad_loc,
                          float *grad_spatial_w, float *grad_level_w, const int64_t *shapes_host,
                          const int64_t *lsi_host, void *workspace, size_t workspace_bytes,
-                         const void *plan, size_t plan_bytes, int hints, void *stream);
+                         const void *plan, size_t plan_bytes, void *state, size_t state_bytes, int hints,
+                        void *stream);
 
 /*
  * ---- reference windows + box offsets -> sampling grid (opt-in; SURVEY.md 8(f) N1, first step) --
@@ -213,14 +224,16 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * slot, the work-item list; 1.4 MB at BoxeR-R50 encoder shapes).  It must stay untouched until the
  * matching *_bwd_ws_* call.  *plan_built is 1 if a plan was built, 0 if the call was just a plain
  * forward (shape not eligible / buffer too small / NULL).
- * state / state_bytes: NULL / 0, or a device buffer of at least boxattn_state_bytes(B, H) bytes, 8-byte aligned (its
- * first KiB are 64-bit counters), that
- * the caller ZEROED ONCE and keeps for the calls it issues on THIS stream: the riders' hand-off tickets.
- * A non-NULL state that is misaligned or too small is an error (hipErrorInvalidValue), not "no state".
- * Every call leaves it zero again, and calls on one stream never overlap, so it is never cleared again.
- * Without it the tickets live in `plan` and a zero-fill launch (~5 us) precedes the forward kernel.
- * The FIRST 1 KiB of the state buffer holds 64 pairs of uint64 counters (the tickets follow; one buffer serves
- * calls of every shape on its stream)
+ * state / state_bytes: NULL / 0, or a device buffer of at least boxattn_state_bytes(dimensions, level tables) bytes,
+ * 8-byte aligned, that the caller ZEROED ONCE and keeps for the calls it issues on ONE stream with ONE set of dimensions
+ * and level shapes (ABI 8; until ABI 7 one buffer served every shape of its stream): counters, the riders' hand-off
+ * tickets (every call leaves them zero), and the record ranges of the backward's one-pass fill (*_bwd_ws_*: for the
+ * shapes that fill takes, the training forward carries nothing of the backward and builds no plan -- *plan_built = 0).
+ * A non-NULL state that is misaligned or too small is an error (hipErrorInvalidValue), not "no state".  The library
+ * remembers (host side) which shape a buffer served last and zeroes a buffer that turns up with another one.
+ * Without a state the tickets live in `plan` and a zero-fill launch (~5 us) precedes the forward kernel.
+ * The FIRST 1 KiB of the state buffer holds 64 pairs of uint64 counters (then 64 bytes of counters of the one-pass
+ * fill: {calls, blocks recomputed because they outgrew their range}; the tickets follow)
  * that the window-staged forward of the encoder case only ever ADDS to: {sample points it had to fetch from
  * global memory because their footprint missed the staged window, sample points inside the window test}.  A
  * caller may read them whenever it likes (e.g. an asynchronous copy after a call; deltas between two reads; a
@@ -231,7 +244,13 @@ int boxattn_grid_bwd_f32(const float *ref, int ref_dim, int ref_per_head, const 
  * 17 against 25 on BoxeR's).  boxer_amd.ops does exactly that.
  */
 #define BOXATTN_HINT_NOT_LOCAL 1
-size_t boxattn_state_bytes(int B, int H);
+/* The state buffer passed with this call was zeroed by the caller since its last call (typically: a newly allocated
+ * one, possibly at an address a released buffer had): the library drops what it remembers (host side) of that address,
+ * so that the backward's first call on it runs the two-pass passes (and plans the ranges) instead of recomputing every
+ * block of a state it believes planned.  Speed only: a zeroed state gives the same results either way. */
+#define BOXATTN_HINT_FRESH_STATE 2
+size_t boxattn_state_bytes(int B, int S, int H, int C, int L, int Lq, int P, const int64_t *shapes_host,
+                           const int64_t *lsi_host);
 size_t boxattn_plan_bytes(int is_bf16, int B, int S, int H, int C, int L, int Lq, int P,
                           const int64_t *shapes_host, const int64_t *lsi_host);
 int boxattn_fwd_train_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -350,7 +369,8 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      0 default (on; chunked blocks are summed inside the accumulate launch wherever the riders run -- maps of up
  *      to 3 072 blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head), and by a
  *      combine launch behind it otherwise), 1 off (launches of their own), 2 on with the combine always a launch of
- *      its own, 3 on with the combine always inside
+ *      its own, 3 on with the combine always inside, 4 on with the two-pass binning of ABI 7 (count riders in the
+ *      training forward, plan hand-over) instead of the one-pass fill into the ranges of the state buffer
  *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
  *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
  *  19  float32 box attention, 32 channels per head: the grad_value accumulate -- 0 default: the bf16 matrix cores on

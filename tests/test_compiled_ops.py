@@ -188,6 +188,8 @@ def test_reference_style_functions_get_the_parked_plan(compiled, dtype, kind):
     one scratch tensor per stream (no device -> host copy and no allocation per call)."""
     import bench
     from boxer_amd import _lib
+    _lib.set_option("riders", 4)     # (two-pass riders: box attention parks a plan too; its default backward -- the
+                                     # one-pass fill -- takes none: test_one_pass_backward_through_the_compiled_module)
     g = golden_io.load("G6_box_ml" if kind == "box" else "G6_inst_ms4")    # (inputs exact in bf16)
     compiled.release_buffers()
     ref_box, ref_inst = bench.reference_style_functions(compiled)
@@ -221,6 +223,37 @@ def test_reference_style_functions_get_the_parked_plan(compiled, dtype, kind):
         with torch.no_grad():          # nothing requires a gradient: an inference forward, nothing parked
             compiled.box_attn_forward(v.detach(), shapes, lsi, l.detach(), a.detach(), 64)
         assert compiled.parked_plans() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_one_pass_backward_through_the_compiled_module(compiled, dtype):
+    """The reference's four functions, default switches: box attention's backward fills its bins in one pass from the
+    ranges in the module's per-geometry state buffer -- the forward parks nothing, and from the second step on the
+    backward launches no count / scan / fill pass of its own; gradients are the golden ones in every step."""
+    import bench
+    from boxer_amd import _lib
+    g = golden_io.load("G6_box_ml")
+    compiled.release_buffers()
+    ref_box, _ = bench.reference_style_functions(compiled)
+    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
+    tol = TOL[dtype]
+    for it in range(3):
+        v = _dev(g["value"], dtype).requires_grad_()
+        l = _dev(g["loc"], torch.float32).requires_grad_()
+        a = _dev(g["attn"], torch.float32).requires_grad_()
+        _lib.profile_begin()
+        try:
+            out = ref_box.apply(v, shapes, lsi, l, a, 64)
+            assert compiled.parked_plans() == 0
+            out.backward(_dev(g["grad_out"], dtype))
+            torch.cuda.synchronize()
+        finally:
+            slots = _lib.profile_end()
+        assert (slots["bwd_binning"]["launches"] > 0) == (it == 0), (it, slots)
+        _close(out, g["out"], tol, "out")
+        _close(v.grad, g["grad_value"], tol, "grad_value (step %d)" % it)
+        _close(a.grad, g["grad_attn"], max(tol, 1e-4), "grad_attn")
 
 
 @pytest.mark.gpu

@@ -283,7 +283,9 @@ def test_riders_match_the_stand_alone_passes(fwd, workload, monkeypatch):
         inp = bench.make_inputs(workload, dtype, "cuda", family="model", batch=2 if workload == "C2" else 1, seed=1)
         v, sh, ls, loc, attn, go = (inp[k] for k in ("value", "shapes", "lsi", "loc", "attn", "grad_out"))
         res = {}
-        for mode in (1, 0, 3):           # own launches | riders (combine: own launch at this size) | riders, combine inside
+        # own launches | default (one-pass fill where the map allows it -- C2 -- else the two-pass riders) | riders with the
+        # combine inside | the two-pass riders of round 4 (count in the forward, plan hand-over)
+        for mode in (1, 0, 3, 4):
             old = lib.boxattn_set_option(OPT_RIDERS, mode)
             try:
                 outs = []
@@ -304,7 +306,7 @@ def test_riders_match_the_stand_alone_passes(fwd, workload, monkeypatch):
             finally:
                 lib.boxattn_set_option(OPT_RIDERS, old)
         ref = res[1][0]
-        for out, gv, gl, ga in res[0] + res[3]:
+        for out, gv, gl, ga in res[0] + res[3] + res[4]:
             assert torch.equal(out, ref[0]) and torch.equal(gl, ref[2]) and torch.equal(ga, ref[3])
             err = (gv.float() - ref[1].float()).abs().max().item()
             # (the order of the records inside a bin, hence the float32 summation order, may differ)

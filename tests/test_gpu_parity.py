@@ -1040,13 +1040,16 @@ def test_bf16_accumulate_single_terms_are_correctly_rounded(C):
     assert worst <= 1.0 + 2.0 ** -7, "worst error %.4f half-ulps" % worst
 
 
+@pytest.mark.parametrize("riders", [0, 4], ids=["one_pass", "two_pass"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_training_forward_plan(dtype):
+def test_training_forward_plan(dtype, riders):
     """box_attn_forward_train counts and scans the sample points' destination bins for the backward
     inside the forward kernel's launch; the backward that receives the plan must give the same
     gradients, and a plan that no longer matches the locations (in-place update) must be ignored,
     not trusted."""
-    from boxer_amd import ops
+    from boxer_amd import _lib, ops
+    _lib.set_option("riders", riders)     # 4: the forward counts and scans (a plan buffer); 0: the backward's one-pass fill
+                                          # needs none -- the plan object then only carries the forward's hints
     g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=41, lo=-0.2, hi=1.2)
     cdt = _cdt(dtype)
     value, loc, attn = dev(g["value"], dtype), dev(g["loc"], cdt), dev(g["attn"], cdt)
@@ -1055,7 +1058,7 @@ def test_training_forward_plan(dtype):
     want = oc.box_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["attn"],
                                 g["grad_out"])
     out, plan = ops.box_attn_forward_train(value, shapes, lsi, loc, attn, 64)
-    assert plan is not None
+    assert plan is not None and (plan.buf is not None) == (riders == 4)
     close(out, want_out, dtype, "out")
     gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, loc, attn, gout, 64, plan=plan)
     close(gv, want[0], dtype, "grad_value (plan)")
@@ -1079,7 +1082,7 @@ def test_training_forward_plan(dtype):
 
 
 def test_training_forward_refuses_a_bad_state_buffer():
-    """include/boxattn.h: a non-NULL state buffer must be 8-byte aligned and boxattn_state_bytes(B, H) bytes long -- a
+    """include/boxattn.h: a non-NULL state buffer must be 8-byte aligned and boxattn_state_bytes(...) bytes long -- a
     buffer that is not is an error (hipErrorInvalidValue = 1), not silently "no state" (which would cost the locality
     counters and a zero-fill launch per forward without anybody noticing)."""
     import ctypes
@@ -1094,8 +1097,10 @@ def test_training_forward_refuses_a_bad_state_buffer():
     sh, ls = np.ascontiguousarray(g["shapes"]), np.ascontiguousarray(g["lsi"])
     nplan = int(lib.boxattn_plan_bytes(0, B, S, H, C, L, Lq, P, sh.ctypes.data, ls.ctypes.data))
     plan = torch.empty(nplan, dtype=torch.uint8, device="cuda")
-    nstate = int(lib.boxattn_state_bytes(B, H))
+    nstate = int(lib.boxattn_state_bytes(B, S, H, C, L, Lq, P, sh.ctypes.data, ls.ctypes.data))
     state = torch.zeros(nstate + 16, dtype=torch.uint8, device="cuda")
+    lib.boxattn_set_option(15, 4)       # the two-pass riders: the training forward builds a plan (the default one-pass
+                                        # fill of the backward needs none: *plan_built stays 0, asserted below)
     built = ctypes.c_int(0)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -1108,6 +1113,10 @@ def test_training_forward_refuses_a_bad_state_buffer():
     assert call(state.data_ptr() + 4, nstate) == 1, "misaligned state"
     assert call(state.data_ptr(), nstate - 8) == 1, "undersized state"
     assert call(0, 0) == 0 and built.value == 1, "no state at all is fine (tickets in the plan buffer)"
+    lib.boxattn_set_option(15, 0)
+    assert call(state.data_ptr(), nstate) == 0 and built.value == 0, "one-pass backward: nothing to hand over"
+    assert call(state.data_ptr(), nstate - 8) == 1, "undersized state"
+    assert call(0, 0) == 0 and built.value == 1, "without a state the backward is the two-pass one: a plan"
     torch.cuda.synchronize()
 
 
@@ -1142,6 +1151,9 @@ def test_reference_api_parks_the_plan(dtype):
     backward (the library's "bwd_binning" timing slot stays empty), same gradients as the oracle's.  A forward
     without gradient requirements parks nothing, and a backward that finds nothing plans for itself."""
     from boxer_amd import _lib, ops
+    # (the two-pass riders of ABI 7, boxattn_set_option(15, 4): the default one-pass fill of the backward takes no plan
+    # -- tests/test_gpu_onepass.py -- but instance attention and the shapes it does not take still park theirs)
+    _lib.set_option("riders", 4)
     g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=47)
     cdt = _cdt(dtype)
     shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
@@ -1191,7 +1203,8 @@ def test_parked_plan_is_not_taken_by_other_tensors():
     """A parked plan names its location / weight tensors by address and version and holds them while it is parked:
     a backward with OTHER tensors of the same shape -- whatever their addresses -- must not get it, and a backward
     after an in-place update of the locations must not either."""
-    from boxer_amd import ops
+    from boxer_amd import _lib, ops
+    _lib.set_option("riders", 4)          # (two-pass riders: the forward parks a plan)
     g = _seeded([(20, 30), (10, 15), (5, 8), (3, 4)], 2, 8, 32, 300, 4, seed=53)
     shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
     v = dev(g["value"], torch.float32).requires_grad_()
