@@ -11,14 +11,14 @@ The compute lives in a C-ABI HIP library (``include/boxattn.h``, ``boxer_amd/csr
 DESIGN.md and INTEGRATION.md.  There is no CPU fallback: ops raise if the library is missing.
 """
 from . import _lib, ops
-from .functions import (BoxAttnBF16Function, BoxAttnFromBoxesFunction, BoxAttnFunction, BoxGridFunction,
+from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
                         InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
                         ValueMaskCastFunction)
 from .modules import Box3dAttention, BoxAttention, InstanceAttention
 
 __all__ = [
     "ops", "BoxAttnFunction", "InstanceAttnFunction", "BoxAttnBF16Function",
-    "InstanceAttnBF16Function", "BoxGridFunction", "BoxAttnFromBoxesFunction", "LogitSoftmaxFunction", "ValueMaskCastFunction",
+    "InstanceAttnBF16Function", "BoxGridFunction", "LogitSoftmaxFunction", "ValueMaskCastFunction",
     "BoxAttention", "InstanceAttention", "Box3dAttention",
     "build", "build_info",
 ]

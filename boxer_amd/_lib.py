@@ -58,15 +58,6 @@ _HL_SIGNATURES = {
     # forward args + shapes_host, lsi_host, stream
     "boxattn_fwd_hl": [_vp] * 5 + _DIMS + [_vp] + [_vp, _vp, _vp],
 }
-_GRIDATTN_SIGNATURES = {
-    # value, shapes, lsi, ref, ref_dim, ref_per_head, offsets, V, angle_mode, kidx, vr, attn, dims, out, grid, stream
-    "boxattn_fwd_grid": [_vp] * 4 + [_i, _i, _vp, _i, _i, _vp, _vp, _vp] + _DIMS + [_vp, _vp, _vp],
-    # value, shapes, lsi, grid, attn, grad_out, ref, ref_dim, ref_per_head, offsets, V, angle_mode, kidx, vr,
-    # dims, grad_value, grad_offsets, grad_ref_rows, grad_attn, shapes_host, lsi_host, ws, ws_bytes, stream
-    "boxattn_bwd_ws_grid": [_vp] * 7 + [_i, _i, _vp, _i, _i, _vp, _vp] + _DIMS + [_vp] * 4 +
-                           [_vp, _vp, _vp, ctypes.c_size_t, _vp],
-}
-NOT_ELIGIBLE = -2
 HINT_NOT_LOCAL = 1          # BOXATTN_HINT_NOT_LOCAL
 HINT_FRESH_STATE = 2        # BOXATTN_HINT_FRESH_STATE
 _ll = ctypes.c_longlong
@@ -88,8 +79,6 @@ EXPORTS = ["boxattn_abi_version", "boxattn_build_info", "boxattn_set_variant", "
            "boxattn_options_epoch",
            "boxattn_set_debug_buffer",
            "boxattn_fwd_hl_f32", "boxattn_fwd_hl_bf16", *sorted(_POINTWISE_SIGNATURES),
-           "boxattn_fwd_grid_f32", "boxattn_fwd_grid_bf16", "boxattn_bwd_ws_grid_f32",
-           "boxattn_bwd_ws_grid_bf16",
            "boxattn_profile_begin", "boxattn_profile_end", "boxattn_bwd_workspace_bytes",
            "boxattn_plan_bytes", "boxattn_state_bytes",
            "boxattn_grid_fwd_f32", "boxattn_grid_bwd_f32"] + [
@@ -212,11 +201,6 @@ def load():
             fn = getattr(lib, "%s_%s" % (stem, suf))
             fn.argtypes = args
             fn.restype = _i
-    for stem, args in _GRIDATTN_SIGNATURES.items():
-        for suf in ("f32", "bf16"):
-            fn = getattr(lib, "%s_%s" % (stem, suf))
-            fn.argtypes = args
-            fn.restype = _i
     lib.boxattn_set_option.argtypes = [_i, _i]
     lib.boxattn_set_option.restype = _i
     lib.boxattn_options_epoch.restype = _i
@@ -250,8 +234,7 @@ def set_variant(v):
     return load().boxattn_set_variant(int(v))
 
 
-OPTIONS = {"bin_chunk": 10, "dense": 11, "dense_jit": 12, "dense_ref": 13, "riders": 15, "dense_fwd": 17,
-           "acc_f32": 19, "ride_shift": 20, "dense_f32": 21}
+OPTIONS = {"bin_chunk": 10, "dense": 11, "riders": 15, "acc_f32": 19, "ride_shift": 20}
 
 
 def set_option(name, value):

@@ -20,7 +20,6 @@
 #include "boxattn_gather2.h"
 #include "boxattn_dense_plan.h"
 #include "boxattn_generic.h"
-#include "boxattn_grid.h"
 
 using namespace boxattn;
 
@@ -33,28 +32,26 @@ std::atomic<int> g_variant{0};
 // Tuning options (boxattn_set_option): process-wide knobs for A/B runs, relaxed atomics.  (The key numbers
 // of rounds 1-3 are kept; the keys of the kernels that lost their A/B and were removed are gone.)
 enum { kOptBinChunk = 10,     // records per work item of the accumulate kernels (0: from the number of sample points)
-       kOptDense = 11,        // window-staged encoder point gradients: 0 default (on), 1 off, 2 on
-       kOptDenseJit = 12,     // window margin for the predicted box offset, tenths of a box quarter (0: 25)
-       kOptDenseRef = 13,     // expected box size in pixels of the query's own level (0: 4, BoxeR's reference windows)
-       kOptRiders = 15,       // count / scan / fill / combine inside the forward, point-gradient and accumulate launches:
-                              // 0 default (on; the combine inside the accumulate launch only for small problems), 1 off
-                              // (launches of their own), 2 on except the combine (its own launch), 3 on, combine inside,
-                              // 4 on, but the two-pass binning of round 4 (count riders in the training forward, fill riders
-                              // against the exact scan) instead of the one-pass fill into guessed ranges (boxattn_spec.h)
-       kOptDenseFwd = 17,     // window-staged matrix-core forward for the encoder case: 0 default (on), 1 off, 2 on
+       kOptDense = 11,        // window-staged encoder kernels (forward + point gradients, bf16 and float32): 0 default (on),
+                              // 1 off (row-gather kernels: the parity cross-check of the two kernel families), 2 on
+       kOptRiders = 15,       // binning passes inside the point-gradient / accumulate (/ forward) launches: 0 default (on; one-pass
+                              // fill where the map allows it, boxattn_spec.h; the combine inside the accumulate launch only
+                              // for small problems), 1 off (launches of their own), 2 on except the combine (its own
+                              // launch), 3 on, combine inside, 4 on with the two-pass binning of round 4 (count riders in the
+                              // training forward, fill riders against the exact scan) instead of the one-pass fill
        kOptAccF32 = 19,       // float32 box attention, C = 32, accumulate: 0 default (bf16 matrix cores on exact three-term
                               // splits), 1 VALU list walk (4-byte records), 2 v_mfma_f32_32x32x2_f32
        kOptRideShift = 20,    // where the riders sit: (s_count + 1) | (s_fill + 1) << 4, a rider group every 2^s groups
                               // of 8 workgroups (s = 0: all in front); | v << 8: 64 v bin workgroups (riders) in all;
                               // 0: defaults
-       kOptDenseF32 = 21,     // window-staged encoder kernels for FLOAT32 box attention: 0 default (on), 1 off (gather kernels)
-       kNumOpts = 22 };
+       kNumOpts = 21 };
+// (round 6 removed the keys whose non-default values had lost their A/B: 12 / 13 window margins, 17 staged forward off,
+// 21 staged float32 kernels off -- 11 = 1 switches every window-staged kernel off)
 std::atomic<int> g_opt[kNumOpts];      // 0 = default
 inline int opt(int k) { return g_opt[k].load(std::memory_order_relaxed); }
 inline bool opt_live(int k)
 {
-    return k == kOptBinChunk || k == kOptDense || k == kOptDenseJit || k == kOptDenseRef || k == kOptRiders ||
-           k == kOptDenseFwd || k == kOptAccF32 || k == kOptRideShift || k == kOptDenseF32;
+    return k == kOptBinChunk || k == kOptDense || k == kOptRiders || k == kOptAccF32 || k == kOptRideShift;
 }
 #ifndef BOXATTN_RIDE_SHIFT_COUNT
 #define BOXATTN_RIDE_SHIFT_COUNT 0     // count riders: all in front of the forward kernel's grid (measured: interleaving
@@ -230,7 +227,6 @@ inline int finish()
 {
     return (int)hipGetLastError();
 }
-constexpr int kNotEligible = BOXATTN_NOT_ELIGIBLE;   // "use the unfused entry points" (no launch was made)
 
 // ---- optional kernel timing (boxattn_profile_begin/_end) -------------------------------
 struct EventPair { hipEvent_t a, b; };
@@ -325,7 +321,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                         out)) {
             if constexpr (!INST && std::is_same<ST, bf16_t>::value) {     // encoder case: window-staged matrix-core forward
                 DensePlan dp;
-                if (allow_dense && opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
+                if (allow_dense && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
                     aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp, 2)) {
                     ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
                     launch_fwd_dense(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(bf16_t)),
@@ -336,7 +332,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             }
             if constexpr (!INST && std::is_same<ST, float>::value) {      // encoder case, float32: window-staged VALU forward
                 DensePlan dp;
-                if (allow_dense && opt(kOptDenseFwd) != 1 && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
+                if (allow_dense && shapes_host && lsi_host && aligned(value, 16) && aligned(out, 16) &&
                     aligned(loc, 8) && make_dense_plan(d, shapes_host, lsi_host, dp, 4)) {
                     ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
                     launch_fwd_dense_f32(value, loc, w_sp, out, dp, (unsigned)(d.n_value() * sizeof(float)),
@@ -381,8 +377,7 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
     hipLaunchKernelGGL((fwd2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>),      \
                        dim3(total, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,       \
                        w_lv, d.S, d.H, d.L, d.Lq, d.P, out, mask,                             \
-                       with_grid(ix, blocks, 1, (d.P + GG - 1) / GG), (unsigned)vbytes,       \
-                       GridSrc{}, ride);
+                       with_grid(ix, blocks, 1, (d.P + GG - 1) / GG), (unsigned)vbytes, ride);
                 BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2);
 #undef BOXATTN_FWD2
                 if (count_ride && ride_taken) *ride_taken = true;
@@ -412,36 +407,6 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
                        n);
     return finish();
 }
-
-// Forward from boxes (GRID flavour of fwd2_kernel): also writes the sampling grid.
-template <typename ST>
-int launch_fwd_grid(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *attn,
-                    const Dims &d, ST *out, const GridSrc &gs, hipStream_t st)
-{
-    if (!d.valid()) return (int)hipErrorInvalidValue;
-    if (d.empty() || d.n_value() == 0) return kNotEligible;
-    if (!value || !shapes || !lsi || !attn || !out || !gs.ref || !gs.offsets || !gs.kidx || !gs.grid_out)
-        return (int)hipErrorInvalidValue;
-    GatherIdx ix{};
-    const size_t vbytes = d.n_value() * sizeof(ST);
-    if (!fast_ok<ST>(d, value, gs.grid_out, out, out, out) || g_variant == 2 || vbytes >= kOobOffset ||
-        !gather_idx(d, ix, sizeof(ST)))
-        return kNotEligible;
-    const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(out, 16));
-    const int blocks = gather_blocks(d, ix, kWave / cfg.G);
-    unsigned total = 0;
-    const BinRide ride = place_riders(nullptr, (unsigned)blocks, &total);
-    ScopedKernelTimer timer(g_prof.ev[kSlotFwd], st);
-#define BOXATTN_FWD2G(GG, VV)                                                                      \
-    hipLaunchKernelGGL((fwd2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV, true>),   \
-                       dim3(total, 1), dim3(256), 0, st, value, shapes, lsi, (const float *)nullptr, \
-                       attn, (const float *)nullptr, d.S, d.H, d.L, d.Lq, d.P, out, (ST *)nullptr, \
-                       with_grid(ix, blocks, 1, 1), (unsigned)vbytes, gs, ride);
-    BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD2G);
-#undef BOXATTN_FWD2G
-    return finish();
-}
-
 
 // ----------------------------------------------------------------------------- backward
 // GV = accumulation buffer for grad_value (the output itself for f32/f64, scratch for bf16)
@@ -626,32 +591,18 @@ inline bool dense_pointgrad_ok(const DensePlan *dp, const void *value, const voi
            aligned(attn, 4) && aligned(grad_loc, 16) && aligned(grad_attn, 16);
 }
 
-// Can the point-gradient kernel reduce the location gradients to box gradients itself (GRID
-// flavour of pointgrad2_kernel: buffered epilogue, one launch row)?
-template <typename ST>
-bool pointgrad_grid_ok(const Dims &d, const void *value, const void *grad_out, const void *grad_sp)
-{
-    GatherIdx ix{};
-    if (d.P != 4 || (d.L * d.P != 16 && d.L * d.P != 8)) return false;
-    if (d.n_value() * sizeof(ST) >= kOobOffset || !gather_idx(d, ix, sizeof(ST))) return false;
-    const GatherCfg cfg = gather_cfg<ST>(d, aligned(value, 16) && aligned(grad_out, 16));
-    if (cfg.G != 4 && cfg.G != 8) return false;
-    const int blocks = gather_blocks(d, ix, kWave / cfg.G);
-    return point_split(blocks, (d.L * d.P + cfg.G - 1) / cfg.G) == 1 && aligned(grad_sp, 16);
-}
-
 // Point gradients (grad_loc / grad_weight): query-major, independent of how grad_value is accumulated;
 // `fill_ride`: the backward's fill pass as rider workgroups of this launch (*ride_taken: carried).
 template <typename ST, int G, bool INST>
 void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi, const float *loc,
                       const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                       const Dims &d, float *grad_loc, float *grad_sp, float *grad_lv, hipStream_t st,
-                      const GridSrc *gs, const BinRide *fill_ride, bool *ride_taken, const DensePlan *dp)
+                      const BinRide *fill_ride, bool *ride_taken, const DensePlan *dp)
 {
     if (ride_taken) *ride_taken = false;
     ScopedKernelTimer timer(g_prof.ev[kSlotBwdPoints], st);
     if constexpr (std::is_same<ST, bf16_t>::value && !INST) {
-        if (!gs && dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
+        if (dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
             launch_pointgrad_dense(value, loc, w_sp, grad_out, *dp, grad_loc, grad_sp,
                                    (unsigned)(d.n_value() * sizeof(bf16_t)), st, fill_ride ? *fill_ride : BinRide{});
             if (fill_ride && ride_taken) *ride_taken = true;
@@ -659,7 +610,7 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
         }
     }
     if constexpr (std::is_same<ST, float>::value && !INST) {
-        if (!gs && dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
+        if (dense_pointgrad_ok(dp, value, loc, w_sp, grad_out, grad_loc, grad_sp)) {
             launch_pointgrad_dense_f32(value, loc, w_sp, grad_out, *dp, grad_loc, grad_sp,
                                        (unsigned)(d.n_value() * sizeof(float)), st, fill_ride ? *fill_ride : BinRide{});
             if (fill_ride && ride_taken) *ride_taken = true;
@@ -687,33 +638,18 @@ void launch_pointgrad(const ST *value, const int64_t *shapes, const int64_t *lsi
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV, true>), \
                    dim3(total, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,    \
                    grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, grad_lv,    \
-                   with_grid(ix, wblocks, split, tiles), (unsigned)vbytes, GridSrc{}, ride);
+                   with_grid(ix, wblocks, split, tiles), (unsigned)vbytes, ride);
             BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2W);
 #undef BOXATTN_PG2W
         } else {
             const int split = point_split(blocks, tiles);
             const BinRide ride = place_riders(fill_ride, (unsigned)blocks, &total);
-            bool done = false;
-            if constexpr (!INST) {
-                if (gs) {        // boxes in, box gradients out (pointgrad_grid_ok() was checked)
-#define BOXATTN_PG2G(GG, VV)                                                                        \
-    if constexpr (GG == 4 || GG == 8)                                                               \
-        hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, false, GatherUnroll<ST, GG, VV>::value, VV,   \
-                                              false, true>),                                        \
-                           dim3(total, 1), dim3(256), 0, st, value, shapes, lsi, loc, w_sp, w_lv,   \
-                           grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp,        \
-                           grad_lv, with_grid(ix, blocks, 1, tiles), (unsigned)vbytes, *gs, ride);
-                    BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2G);
-#undef BOXATTN_PG2G
-                    done = true;
-                }
-            }
-            if (!done) {
+            {
 #define BOXATTN_PG2(GG, VV)                                                                   \
 hipLaunchKernelGGL((pointgrad2_kernel<ST, GG, INST, GatherUnroll<ST, GG, VV>::value, VV>), \
                    dim3(total, split), dim3(256), 0, st, value, shapes, lsi, loc, w_sp,    \
                    w_lv, grad_out, grad_mask, d.S, d.H, d.L, d.Lq, d.P, grad_loc, grad_sp, \
-                   grad_lv, with_grid(ix, blocks, split, tiles), (unsigned)vbytes, GridSrc{}, ride);
+                   grad_lv, with_grid(ix, blocks, split, tiles), (unsigned)vbytes, ride);
                 BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_PG2);
 #undef BOXATTN_PG2
             }
@@ -780,7 +716,7 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
                const float *w_sp, const float *w_lv, const ST *grad_out, const ST *grad_mask,
                const Dims &d, const BinPlan &plan, const PlanLayout &pl, char *pbuf, const ScratchLayout &sl,
                char *sbuf, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv, bool plan_ready,
-               hipStream_t st, const GridSrc *gs, const DensePlan *dp, const SpecRide *spec = nullptr,
+               hipStream_t st, const DensePlan *dp, const SpecRide *spec = nullptr,
                bool spec_warm = false, int *spec_tickets = nullptr)
 {
     const int ns = d.B * d.H;
@@ -800,16 +736,16 @@ int run_binned(const ST *value, const int64_t *shapes, const int64_t *lsi, const
         ride.spec = *spec;
         ride.tickets = spec_tickets;
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
-                                      grad_sp, grad_lv, st, gs, &ride, &filled, dp);
+                                      grad_sp, grad_lv, st, &ride, &filled, dp);
         if (!filled)        // (the launched kernel carries no riders: the two-pass passes as launches, below)
             launch_binning(flavour, loc, w_sp, d, plan, pl, pbuf, records, st, kBinCount | kBinScan);
     } else if (riders_ok(plan, pl)) {
         const BinRide ride = make_ride(loc, w_sp, d, plan, pl, pbuf, &sl, sbuf, flavour, true);
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
-                                      grad_sp, grad_lv, st, gs, &ride, &filled, dp);
+                                      grad_sp, grad_lv, st, &ride, &filled, dp);
     } else {
         launch_pointgrad<ST, G, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, d, grad_loc,
-                                      grad_sp, grad_lv, st, gs, nullptr, nullptr, dp);
+                                      grad_sp, grad_lv, st, nullptr, nullptr, dp);
     }
     // Chunked blocks: summed by their last chunk inside the accumulate launch (chunk_finish; the fill pass -- riding
     // or not -- clears the blocks' tickets) wherever the riders run: one launch less, C2 bf16 125.7 -> 122.9 us, C2 fp32
@@ -854,7 +790,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   const Dims &d, ST *grad_value, float *grad_loc, float *grad_sp, float *grad_lv,
                   const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
                   size_t workspace_bytes, const void *plan_buf, size_t plan_bytes, int hints, hipStream_t st,
-                  const GridSrc *gs = nullptr, void *state = nullptr, size_t state_bytes = 0)
+                  void *state = nullptr, size_t state_bytes = 0)
 {
     constexpr bool kBf16 = std::is_same<ST, bf16_t>::value;
     if (!d.valid()) return (int)hipErrorInvalidValue;
@@ -865,8 +801,6 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
                   fast_ok<ST>(d, value, loc, grad_out,
                               INST ? (const void *)grad_mask : (const void *)grad_out, grad_loc) &&
                   aligned(workspace, 256) && aligned(grad_value, 16);
-    if (gs && (!binned || INST || !pointgrad_grid_ok<ST>(d, value, grad_out, grad_sp)))
-        return kNotEligible;                 // the caller falls back to the grid tensor's own kernels
     PlanLayout pl{};
     ScratchLayout sl{};
     bool plan_ready = false;
@@ -876,9 +810,6 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
         plan_ready = plan_buf && plan_bytes >= pl.total && aligned(plan_buf, 256);
         binned = workspace_bytes >= (plan_ready ? sl.total : pl.total + sl.total);
     }
-    // the boxes-in entry points never take the atomic fallback (its grad_loc slot is aliased to
-    // grad_offsets there, a smaller buffer): an undersized workspace is "not eligible"
-    if (gs && !binned) return kNotEligible;
     if (!binned) {
         // (a plan the forward built is simply not used when the backward's own checks -- e.g. an
         // unaligned grad_out view -- rule the binned path out: the atomic path needs no plan)
@@ -908,7 +839,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     const SpecRide *sp = nullptr;
     bool spec_warm = false;
     int *spec_tickets = nullptr;
-    if (!gs && !plan_ready && spec_ok<ST, INST>(d, plan, pl)) {
+    if (!plan_ready && spec_ok<ST, INST>(d, plan, pl)) {
         const StateLayout sy = state_layout(d, &plan);
         const int chk = state_check(state, state_bytes, sy, d, shapes_host, st, (hints & BOXATTN_HINT_FRESH_STATE) != 0);
         if (chk < 0) return (int)hipErrorInvalidValue;
@@ -927,7 +858,7 @@ int launch_bwd_ws(const ST *value, const int64_t *shapes, const int64_t *lsi, co
     case GG:                                                                                    \
         rc = run_binned<ST, GG, INST>(value, shapes, lsi, loc, w_sp, w_lv, grad_out, grad_mask, \
                                       d, plan, pl, pbuf, sl, sbuf, grad_value, grad_loc, grad_sp, grad_lv, \
-                                      plan_ready, st, gs, dp, sp, spec_warm, spec_tickets);     \
+                                      plan_ready, st, dp, sp, spec_warm, spec_tickets);     \
         break;
         BOXATTN_BINNED_CASE(4)
         BOXATTN_BINNED_CASE(8)
@@ -1096,7 +1027,7 @@ int boxattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t 
 {
     return launch_bwd_ws<float, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                        grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                       workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
+                                       workspace, workspace_bytes, plan, plan_bytes, hints, ST_, state, state_bytes);
 }
 int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *attn, const uint16_t *grad_out, int B,
@@ -1108,7 +1039,7 @@ int boxattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int6
 {
     return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, loc, attn, nullptr, grad_out, nullptr, DIMS,
                                         grad_value, grad_loc, grad_attn, nullptr, shapes_host, lsi_host,
-                                        workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
+                                        workspace, workspace_bytes, plan, plan_bytes, hints, ST_, state, state_bytes);
 }
 int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *loc, const float *spatial_w, const float *level_w,
@@ -1121,7 +1052,7 @@ int instattn_bwd_ws_f32(const float *value, const int64_t *shapes, const int64_t
 {
     return launch_bwd_ws<float, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                       grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
+                                      lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, state, state_bytes);
 }
 int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *spatial_w, const float *level_w,
@@ -1134,7 +1065,7 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
 {
     return launch_bwd_ws<bf16_t, true>(value, shapes, lsi, loc, spatial_w, level_w, grad_out, grad_mask, DIMS,
                                        grad_value, grad_loc, grad_spatial_w, grad_level_w, shapes_host,
-                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, nullptr, state, state_bytes);
+                                       lsi_host, workspace, workspace_bytes, plan, plan_bytes, hints, ST_, state, state_bytes);
 }
 
 
@@ -1312,97 +1243,5 @@ int instattn_bwd_bf16(const uint16_t *value, const int64_t *shapes, const int64_
                                     grad_level_w, grad_value_ws, ST_);
 }
 
-
-// ---- reference windows + offsets -> sampling grid ------------------------------------------
-static int grid_dims(int ref_dim, int ref_per_head, int V, int angle_mode, int B, int Lq, int H,
-                     int L, int P, GridDims &d)
-{
-    if (B < 0 || Lq < 0 || H <= 0 || L <= 0 || P <= 0 || angle_mode < 0 || angle_mode > 2)
-        return 0;
-    if (V != (angle_mode == 1 ? 5 : 4) || ref_dim < (angle_mode ? 5 : 4)) return 0;
-    d = GridDims{Lq, H, L, P, V, ref_dim, ref_per_head ? 1 : 0, angle_mode};
-    return ((size_t)B * Lq == 0) ? 2 : 1;                       // 2: nothing to do
-}
-
-// ---- box attention straight from boxes (second step) ----------------------
-static int grid_src(const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                    int angle_mode, const float *kernel_idx, const float *valid_ratios, int B, int Lq,
-                    int H, int L, int P, GridSrc &gs)
-{
-    GridDims gd{};
-    const int ok = grid_dims(ref_dim, ref_per_head, V, angle_mode, B, Lq, H, L, P, gd);
-    if (ok != 1 || !ref || !offsets || !kernel_idx) return ok == 2 ? BOXATTN_NOT_ELIGIBLE : (int)hipErrorInvalidValue;
-    gs = GridSrc{ref, offsets, kernel_idx, valid_ratios, gd, nullptr, nullptr, nullptr};
-    return 0;
-}
-
-int boxattn_fwd_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                         const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                         int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                         const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
-                         float *out, float *grid, void *stream)
-{
-    GridSrc gs;
-    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
-                          B, Lq, H, L, P, gs))
-        return rc;
-    gs.grid_out = grid;
-    return launch_fwd_grid<float>(value, shapes, lsi, attn, DIMS, out, gs, ST_);
-}
-int boxattn_fwd_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
-                          const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                          int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                          const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
-                          uint16_t *out, float *grid, void *stream)
-{
-    GridSrc gs;
-    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
-                          B, Lq, H, L, P, gs))
-        return rc;
-    gs.grid_out = grid;
-    return launch_fwd_grid<bf16_t>(value, shapes, lsi, attn, DIMS, out, gs, ST_);
-}
-int boxattn_bwd_ws_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                            const float *grid, const float *attn, const float *grad_out,
-                            const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                            int angle_mode, const float *kernel_idx, const float *valid_ratios, int B,
-                            int S, int H, int C, int L, int Lq, int P, float *grad_value,
-                            float *grad_offsets, float *grad_ref_rows, float *grad_attn,
-                            const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                            size_t workspace_bytes, void *stream)
-{
-    GridSrc gs;
-    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
-                          B, Lq, H, L, P, gs))
-        return rc;
-    if (!grad_offsets) return (int)hipErrorInvalidValue;
-    gs.grad_offsets = grad_offsets;
-    gs.grad_ref_rows = grad_ref_rows;
-    return launch_bwd_ws<float, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
-                                       DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
-                                       grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                       workspace_bytes, nullptr, 0, 0, ST_, &gs);
-}
-int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
-                             const float *grid, const float *attn, const uint16_t *grad_out,
-                             const float *ref, int ref_dim, int ref_per_head, const float *offsets,
-                             int V, int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                             int B, int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
-                             float *grad_offsets, float *grad_ref_rows, float *grad_attn,
-                             const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                             size_t workspace_bytes, void *stream)
-{
-    GridSrc gs;
-    if (int rc = grid_src(ref, ref_dim, ref_per_head, offsets, V, angle_mode, kernel_idx, valid_ratios,
-                          B, Lq, H, L, P, gs))
-        return rc;
-    if (!grad_offsets) return (int)hipErrorInvalidValue;
-    gs.grad_offsets = grad_offsets;
-    gs.grad_ref_rows = grad_ref_rows;
-    return launch_bwd_ws<bf16_t, false>(value, shapes, lsi, grid, attn, nullptr, grad_out, nullptr,
-                                        DIMS, grad_value, grad_offsets /* unused grad_loc slot */,
-                                        grad_attn, nullptr, shapes_host, lsi_host, workspace,
-                                        workspace_bytes, nullptr, 0, 0, ST_, &gs);
-}
 
 }  // extern "C"

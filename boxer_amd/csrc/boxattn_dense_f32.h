@@ -23,8 +23,10 @@ namespace boxattn {
 
 constexpr int kDenseF32Slot = 128;                 // one staged pixel: 32 float32 channels
 constexpr int kDenseF32Unit = 32;                  // bytes per unit of DenseWin::geo's pitch / offset fields
-#ifndef BOXATTN_DENSE_F32_LDS
-#define BOXATTN_DENSE_F32_LDS 53248                // 52 KB: three workgroups per CU (BoxeR-R50 tiles need 50.8 KB)
+// (BOXATTN_DENSE_F32_LDS -- 52 KB: three workgroups per CU, BoxeR-R50 tiles need 50.8 KB -- is defined ONCE, in
+// boxattn_dense_plan.h, next to the host's window budget that must agree with it)
+#ifndef BOXATTN_DENSE_F32_SKEW
+#define BOXATTN_DENSE_F32_SKEW 32
 #endif
 constexpr int kDenseF32LdsBytes = BOXATTN_DENSE_F32_LDS;
 constexpr int kDenseF32ZeroOff = kDenseF32LdsBytes - kDenseF32Slot;    // the forward's row of zeros (make_dense_plan leaves it free)
@@ -34,7 +36,15 @@ struct DenseWinPosF32 {
     int x0, y0;
     __device__ __forceinline__ int rows() const { return (int)(geo & 31u); }
     __device__ __forceinline__ int cols() const { return (int)((geo >> 5) & 31u); }
-    __device__ __forceinline__ int pitchb() const { return (int)((geo >> 10) & 127u) * kDenseF32Unit; }
+    // Bytes between window rows: the row's pixels + a skew of 32 bytes (one unit of the host's pitch field).  A lane reads
+    // a corner row as eight 16-byte pieces, every lane of an instruction piece i of ITS row, and rows and pixels start at
+    // multiples of 32 bytes: only 8 of the 16 bank groups ever hold a piece i (half of the kernels' LDS-busy time is bank
+    // conflicts, profiles/r05_pmc_sq_fp32.txt).  A skew of 16 bytes -- consecutive rows then step through all 16 groups --
+    // was measured in round 6 (-DBOXATTN_DENSE_F32_SKEW=16, same box, C2 / C2' float32): 210.0 / 342.9 us a step against
+    // 210.7 / 342.5: nothing (profiles/r06_f32_skew.log) -- the lanes of a wave read few distinct ROWS (a 4 x 4 query
+    // sub-tile), what collides are pixels of one row, 128 bytes apart, and a direct-to-LDS load cannot pad between the
+    // pixels it writes (lane-linear destination).
+    __device__ __forceinline__ int pitchb() const { return cols() * kDenseF32Slot + BOXATTN_DENSE_F32_SKEW; }
     __device__ __forceinline__ int offb() const { return (int)(geo >> 17) * kDenseF32Unit; }
 };
 

@@ -27,7 +27,6 @@
 #pragma once
 #include "boxattn_device.h"
 #include "boxattn_fast.h"
-#include "boxattn_grid.h"
 #include "boxattn_binned.h"
 #include "boxattn_binpass.h"
 
@@ -289,19 +288,14 @@ __device__ __forceinline__ unsigned pair_of_lane(const GatherIdx &ix, unsigned b
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-// GRID (box attention only; SURVEY.md 8(f) N1, second step): the sampling locations are not read
-// but computed from the boxes (gs: reference windows + predicted offsets, the grid math of
-// boxattn_grid.h) by the lane that locates the point, and stored to gs.grid_out on the way (the
-// backward's kernels read them).
-template <typename ST, int G, bool INST, int U, int VEC, bool GRID = false>
+template <typename ST, int G, bool INST, int U, int VEC>
 __global__ __launch_bounds__(256) void fwd2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
-    GridSrc gs, BinRide ride)
+    BinRide ride)
 {
-    static_assert(!(GRID && INST), "boxes -> grid is built for box attention");
     constexpr int C = VEC * G, PAIRS = kWave / G, NH = INST ? 3 : 2;
     // the training forward: the backward's count pass and the scans chained behind it ride in this launch
     // (boxattn_ride.h, bin_count_ride)
@@ -354,11 +348,6 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                 const int lq = have ? lp : LP - 1;
                 const int l = (int)(((float)lq + 0.5f) * rcp_p);   // lq / P (exact, see rcp_p)
                 const float a = have ? a_in : 0.f;
-                if constexpr (GRID) {                             // the point from its box
-                    const GridBox gb = grid_box(gs.ref, gs.offsets, gs.vr, gs.d, (size_t)qh * L + l);
-                    xy = grid_point(gb, gs.kidx, lq - l * P, gs.vr != nullptr, gs.d.angle_mode);
-                    if (have && active) reinterpret_cast<float2 *>(gs.grid_out)[pt0 + lq] = xy;
-                }
                 const Sample<float> s = locate<float>(xy.x, xy.y, lv.h[l], lv.w[l]);
                 const u32x4_t off =
                     corner_offsets<ST>(s, b * (unsigned)S + (unsigned)lv.start[l], H, h, C, have);
@@ -418,7 +407,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
         // look-ahead the kernel ran at the HBM LATENCY of that stream (4 dependent round trips
         // per wave, 1.6 TB/s on 54 MB).  BoxeR's shape (L P = 4 G: 4 levels x 2 x 2 points, 4
         // lanes per pair) requests all four tiles up front -- one round trip per wave.
-        if (kGatherPreload && !GRID && G == 4 && LP == kPreTiles * G) {
+        if (kGatherPreload && G == 4 && LP == kPreTiles * G) {
             float2 xy4[kPreTiles];
             float a4[kPreTiles];
 #pragma unroll
@@ -439,8 +428,7 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                 }
             }
         } else {
-            float2 xy_n = make_float2(0.f, 0.f);
-            if constexpr (!GRID) xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
+            float2 xy_n = loc2[pt0 + min(slot, LP - 1)];            // tile 0
             float a_n = w_sp[pt0 + min(slot, LP - 1)];
             levels_commit(lv, lv_regs, L);
             for (int t0 = 0; t0 < LP; t0 += G) {
@@ -449,11 +437,11 @@ __global__ __launch_bounds__(256) void fwd2_kernel(
                 const int lp = t0 + slot;
                 if constexpr (kGatherPrefetch) {
                     const int nq = min(lp + G, LP - 1);           // same point again past the end
-                    if constexpr (!GRID) xy_n = loc2[pt0 + nq];
+                    xy_n = loc2[pt0 + nq];
                     a_n = w_sp[pt0 + nq];
                 } else {
                     const int lq = min(lp, LP - 1);
-                    if constexpr (!GRID) xy = loc2[pt0 + lq];
+                    xy = loc2[pt0 + lq];
                     a = w_sp[pt0 + lq];
                 }
                 tile(t0, xy, a);
@@ -709,20 +697,15 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
 // attention): all lane groups of a wave work on ONE (query, head) pair, group g on the point
 // tiles g, g + 16, ...: the wave's results are 64 consecutive points (whole lines instead of
 // 16- and 32-byte pieces 3 KiB apart) and its location / weight reads are contiguous.
-// GRID (box attention, the buffered epilogue's shapes: L * P = 8 or 16, P = 4): the location
-// gradients of a (query, head, level) row are reduced to the box gradient in the epilogue
-// (grid_grad_add / grid_grad_store of boxattn_grid.h: what grid_bwd_kernel does) and written as
-// gs.grad_offsets (+ gs.grad_ref_rows); grad_loc is not written.
-template <typename ST, int G, bool INST, int U, int VEC, bool WP = false, bool GRID = false>
+template <typename ST, int G, bool INST, int U, int VEC, bool WP = false>
 __global__ __launch_bounds__(256) void pointgrad2_kernel(
     const ST *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv,
     const ST *__restrict__ grad_out, const ST *__restrict__ grad_mask, int S, int H, int L,
     int Lq, int P, float *__restrict__ grad_loc, float *__restrict__ grad_sp,
-    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, GridSrc gs, BinRide ride)
+    float *__restrict__ grad_lv, GatherIdx ix, unsigned value_bytes, BinRide ride)
 {
-    static_assert(!GRID || (!INST && !WP && (G == 4 || G == 8)), "needs the buffered epilogue");
     constexpr int C = VEC * G, PAIRS = kWave / G;
     // the backward's fill pass rides in this launch (boxattn_ride.h, bin_fill_ride)
     __shared__ int ride_lds[kRideLdsInts];
@@ -828,8 +811,7 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
     }
     levels_commit(lv, lv_regs, L);
     const bool buffered = kCanBuffer && !WP && ix.grid_y == 1 && (LP == 16 || LP == 8) &&
-                          (((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0 ||
-                           GRID);      // (GRID: the host has checked; grad_loc is not used)
+                          ((reinterpret_cast<uintptr_t>(grad_sp) | reinterpret_cast<uintptr_t>(grad_loc)) & 15) == 0;
     float *res = res_all + (kCanBuffer ? (wv * PAIRS + lane / G) * (kBufLP * 3) : 0);
     if constexpr (BOXATTN_TUNE_PG_TRACE) ts[ts_n++] = __builtin_amdgcn_s_memtime();
     // (wave-uniform trip count: with WP the groups whose tile lies past the end idle)
@@ -965,39 +947,16 @@ __global__ __launch_bounds__(256) void pointgrad2_kernel(
             const int n = LP / G, p0 = slot * n;              // this lane's points of the pair: 1, 2 or 4
             const float *r = res + kBufLP + 2 * p0;
             float *gsp = grad_sp + pt0 + p0, *gl = grad_loc + 2 * (pt0 + p0);
-            if constexpr (GRID) {
-                // my n points belong to one (query, head, level) row (P = 4, n in {1, 2, 4}); the
-                // row's other points sit in the neighbouring lanes of the quad
-                const int l = p0 / P;
-                const size_t row = (size_t)qh * L + l;
-                const GridBox gb = grid_box(gs.ref, gs.offsets, gs.vr, gs.d, row);
-                GridGrad ag{0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int i = 0; i < n; ++i)
-                    grid_grad_add(ag, gb, gs.kidx, (p0 + i) % P, make_float2(r[2 * i], r[2 * i + 1]));
-                if (n == 2) {                          // two lanes per row
-                    ag.cx = group_sum<2>(ag.cx); ag.cy = group_sum<2>(ag.cy);
-                    ag.w = group_sum<2>(ag.w); ag.h = group_sum<2>(ag.h); ag.t = group_sum<2>(ag.t);
-                } else if (n == 1) {                   // four
-                    ag.cx = group_sum<4>(ag.cx); ag.cy = group_sum<4>(ag.cy);
-                    ag.w = group_sum<4>(ag.w); ag.h = group_sum<4>(ag.h); ag.t = group_sum<4>(ag.t);
-                }
-                if (p0 % P == 0)
-                    grid_grad_store(ag, gb, gs.offsets + row * (unsigned)gs.d.V, gs.d,
-                                    gs.grad_offsets + row * (unsigned)gs.d.V,
-                                    gs.grad_ref_rows ? gs.grad_ref_rows + row * 5 : nullptr);
-            }
             if (n == 4) {
                 *reinterpret_cast<float4 *>(gsp) = make_float4(res[p0], res[p0 + 1], res[p0 + 2], res[p0 + 3]);
-                if constexpr (!GRID) {
-                    reinterpret_cast<float4 *>(gl)[0] = make_float4(r[0], r[1], r[2], r[3]);
-                    reinterpret_cast<float4 *>(gl)[1] = make_float4(r[4], r[5], r[6], r[7]);
-                }
+                reinterpret_cast<float4 *>(gl)[0] = make_float4(r[0], r[1], r[2], r[3]);
+                reinterpret_cast<float4 *>(gl)[1] = make_float4(r[4], r[5], r[6], r[7]);
             } else if (n == 2) {
                 *reinterpret_cast<float2 *>(gsp) = make_float2(res[p0], res[p0 + 1]);
-                if constexpr (!GRID) *reinterpret_cast<float4 *>(gl) = make_float4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<float4 *>(gl) = make_float4(r[0], r[1], r[2], r[3]);
             } else {
                 *gsp = res[p0];
-                if constexpr (!GRID) *reinterpret_cast<float2 *>(gl) = make_float2(r[0], r[1]);
+                *reinterpret_cast<float2 *>(gl) = make_float2(r[0], r[1]);
             }
         }
     }

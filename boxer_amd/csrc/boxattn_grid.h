@@ -114,15 +114,4 @@ __device__ __forceinline__ void grid_grad_store(GridGrad a, const GridBox &g, co
     }
 }
 
-// What the sampling kernels need to work from boxes (second step): the
-// forward computes every point's location from its box and also stores the grid (the backward's
-// kernels read it); the point-gradient kernel reduces the location gradients of a (query, head,
-// level) row to grad_offsets / grad_ref_rows itself instead of writing grad_loc.
-struct GridSrc {
-    const float *ref, *offsets, *kidx, *vr;
-    GridDims d;
-    float *grid_out;                  // forward
-    float *grad_offsets, *grad_ref_rows;   // backward (grad_ref_rows may be null)
-};
-
 }  // namespace boxattn

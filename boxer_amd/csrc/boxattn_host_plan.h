@@ -301,7 +301,6 @@ inline void state_learned(const void *state)
 inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls, DensePlan &p, int elem)
 {
     if (!sh || !ls || !d.valid() || opt(kOptDense) == 1 || g_variant == 1 || g_variant == 2) return false;
-    if (elem == 4 && opt(kOptDenseF32) == 1) return false;
     if (d.Lq != d.S || d.C != 32 || d.P != 4 || d.L > kDenseMaxLevels || d.B < 1 || d.S < 1) return false;
     if ((size_t)d.B * d.Lq * d.H * d.L * d.P >= (1ull << 31)) return false;       // 32-bit point ids
     if (d.n_value() * (size_t)elem >= kOobOffset) return false;
@@ -332,8 +331,8 @@ inline bool make_dense_plan(const Dims &d, const int64_t *sh, const int64_t *ls,
     // ref / 4 * r here) to either side, the predicted offset may move them `jit` quarters further.
     // The windows share the workgroup's kDenseLdsBytes of LDS; what does not fit (a coarse tile's window on a
     // fine level) is not staged.
-    const float ref4 = (opt(kOptDenseRef) > 0 ? (float)opt(kOptDenseRef) : 4.0f) / 4.0f;
-    const float jit = (opt(kOptDenseJit) > 0 ? (float)opt(kOptDenseJit) : 25.0f) / 10.0f;
+    constexpr float ref4 = 4.0f / 4.0f;     // expected box: 4 pixels of the query's own level (BoxeR's reference windows)
+    constexpr float jit = 2.5f;             // margin for the predicted offsets, in box quarters
     for (int lq = 0; lq < d.L; ++lq) {
         int used = 0;
         // the tile's OWN level first -- its window serves the most points and must never be the one that does not

@@ -252,65 +252,3 @@ def _ref_grad(ref_windows, rows):
     n = min(5, ref_windows.size(-1))
     grad_ref[..., :n] = rows[..., :n]
     return grad_ref
-
-
-class BoxAttnFromBoxesFunction(Function):
-    """(value, shapes, lsi, ref_windows, offsets, kernel_indices, valid_ratios, angle_mode,
-    attention_weights, native_bf16) -> output: box attention with the sampling grid built INSIDE
-    the sampling kernels (``module.fused_grid = 2``; SURVEY.md 8(f) N1, second step).  The forward
-    computes the points from the boxes (and keeps the grid for the backward), the backward's
-    point-gradient kernel emits grad_offsets / the reference windows' gradient directly: no
-    grad_loc tensor, no separate grid kernels.  Shapes the fused kernels are not built for run
-    BoxGridFunction's kernels + the plain operator instead (same results)."""
-
-    @staticmethod
-    @custom_fwd(device_type="cuda")
-    def forward(ctx, value, shapes, lsi, ref_windows, offsets, kernel_indices, valid_ratios,
-                angle_mode, attention_weights, native_bf16):
-        # no cast_inputs: under autocast a bf16 value (ValueMaskCastFunction's output) would be
-        # widened to float32 by the decorator and narrowed again here -- two passes over B*S*d.
-        # (Without cast_inputs custom_fwd leaves the caller's autocast state ON inside forward and
-        # custom_bwd restores it in backward: harmless here because every operation of both bodies is
-        # a C-ABI call or an explicit cast -- keep it that way, or wrap new torch math in
-        # torch.autocast("cuda", enabled=False).)
-        ctx.value_dtype = value.dtype                # the caller's type: grad_value goes back in it
-        if native_bf16:
-            value = value if value.dtype == torch.bfloat16 else value.to(torch.bfloat16)
-        else:
-            value = value.float()
-        value = value.contiguous()
-        ref_windows, offsets = ref_windows.float().contiguous(), offsets.float().contiguous()
-        kernel_indices = kernel_indices.float().contiguous()
-        attn = attention_weights.float().contiguous()
-        if valid_ratios is not None:
-            valid_ratios = valid_ratios.float().contiguous()
-        res = ops.box_attn_forward_from_boxes(value, shapes, lsi, ref_windows, offsets,
-                                              kernel_indices, valid_ratios, angle_mode, attn)
-        if res is None:                     # not a shape of the fused kernels
-            grid = ops.box_grid_forward(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode)
-            out = ops.box_attn_forward(value, shapes, lsi, grid, attn, 64)
-        else:
-            out, grid = res
-        ctx.save_for_backward(value, shapes, lsi, grid, attn, ref_windows, offsets, kernel_indices,
-                              valid_ratios)
-        ctx.angle_mode = angle_mode
-        return out
-
-    @staticmethod
-    @once_differentiable
-    @custom_bwd(device_type="cuda")
-    def backward(ctx, grad_output):
-        value, shapes, lsi, grid, attn, ref_windows, offsets, kidx, vr = ctx.saved_tensors
-        grad_output = grad_output.contiguous().to(value.dtype)
-        need_ref = ctx.needs_input_grad[3]
-        res = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, grad_output,
-                                             ref_windows, offsets, kidx, vr, ctx.angle_mode,
-                                             need_ref_grad=need_ref)
-        if res is None:
-            gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, grid, attn, grad_output, 64)
-            go, rows = ops.box_grid_backward(ref_windows, offsets, kidx, vr, ctx.angle_mode, gl,
-                                             need_ref_grad=need_ref)
-        else:
-            gv, go, rows, ga = res
-        grad_ref = _ref_grad(ref_windows, rows) if need_ref else None
-        return (gv.to(ctx.value_dtype), None, None, grad_ref, go, None, None, None, ga, None)

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import dense
-from .functions import (BoxAttnBF16Function, BoxAttnFromBoxesFunction, BoxAttnFunction, BoxGridFunction,
+from .functions import (BoxAttnBF16Function, BoxAttnFunction, BoxGridFunction,
                         InstanceAttnBF16Function, InstanceAttnFunction, LogitSoftmaxFunction,
                         ValueMaskCastFunction)
 
@@ -49,9 +49,10 @@ class _BoxAttentionBase(nn.Module):
         self.head_dim = d_model // num_head
         self.kernel_size = kernel_size
         self.native_bf16 = False
-        # opt-in: True / 1 = box -> grid expansion in one HIP kernel each way (BoxGridFunction);
-        # 2 = the grid is built inside the sampling kernels (BoxAttnFromBoxesFunction): no
-        # separate grid kernels, no grad_loc tensor (BoxAttention / Box3dAttention)
+        # opt-in: box -> grid expansion in one HIP kernel each way (BoxGridFunction).  (Until round
+        # 5 the value 2 built the grid inside the sampling kernels; it never removed the grid tensor -- both bin passes
+        # and the point gradients read it -- and was no faster than the one-kernel grid build: removed in round 6, any
+        # true value means the grid kernels.)
         self.fused_grid = False
         # opt-in: the softmax over the L*P logits and, in the bf16 storage mode, the value
         # mask-fill + bf16 cast as single HIP passes (LogitSoftmaxFunction, ValueMaskCastFunction)
@@ -159,15 +160,9 @@ class BoxAttention(_BoxAttentionBase):
     def forward(self, query, value, v_shape, v_mask, v_start_index, v_valid_ratios, ref_windows):
         value = self._project_value(value, v_mask)
         attn_weights = self._softmax_weights(query)
-        if self.fused_grid == 2 and self._use_fused_grid(query, v_valid_ratios):
-            offsets = self._box_offsets(query, ref_windows, 5 if self._angle_mode() == 1 else 4)
-            output = BoxAttnFromBoxesFunction.apply(
-                value, v_shape, v_start_index, ref_windows, offsets, self.kernel_indices,
-                v_valid_ratios, self._angle_mode(), attn_weights, self.native_bf16)
-        else:
-            sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
-            output = self._box_function().apply(value, v_shape, v_start_index, sampled_grid,
-                                                attn_weights, self.im2col_step)
+        sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
+        output = self._box_function().apply(value, v_shape, v_start_index, sampled_grid,
+                                            attn_weights, self.im2col_step)
         return dense.linear(output, self.out_proj.weight, self.out_proj.bias), attn_weights
 
 

@@ -583,7 +583,7 @@ def instance_attn_backward(value, spatial_shapes, level_start_index, sampling_lo
 
 # ---------------------------------------------------------------------------------------
 # reference windows + box offsets -> sampling grid (opt-in, beyond the reference's native
-# module; SURVEY.md 8(f) N1, first step)
+# module)
 # ---------------------------------------------------------------------------------------
 def _grid_args(ref_windows, offsets, kernel_indices, valid_ratios, angle_mode):
     _check(ref_windows, "ref_windows")
@@ -703,68 +703,3 @@ def value_mask_cast(value, v_mask):
     out = torch.empty(value.shape, dtype=torch.bfloat16, device=value.device)
     _grid_call("boxattn_value_prep_" + _pw_suffix(value, "value"), value, value, mask, rows, d, out)
     return out
-
-
-# ---------------------------------------------------------------------------------------
-# box attention straight from boxes (opt-in; SURVEY.md 8(f) N1, second step)
-# ---------------------------------------------------------------------------------------
-def box_attn_forward_from_boxes(value, spatial_shapes, level_start_index, ref_windows, offsets,
-                                kernel_indices, valid_ratios, angle_mode, attn_weight):
-    """-> (output (B,Lq,H*C), sampling grid (B,Lq,H,L,P,2)) or None when the fused kernels do not
-    apply to the shape (use box_grid_forward + box_attn_forward then).  The forward computes every
-    sample point from its box and stores the grid on the way."""
-    (B, Lq, H, L, P), (D, per_head, V, mode) = _grid_args(ref_windows, offsets, kernel_indices,
-                                                           valid_ratios, angle_mode)
-    grid = torch.empty((B, Lq, H, L, P, 2), dtype=torch.float32, device=value.device)
-    dims, _, (attn,), _ = _prepare(value, spatial_shapes, level_start_index, grid, [attn_weight])
-    if value.dtype not in (torch.float32, torch.bfloat16) or attn.dtype != torch.float32:
-        return None
-    out = torch.empty((B, Lq, dims[2] * dims[3]), dtype=value.dtype, device=value.device)
-    fn = getattr(_lib.load(), "boxattn_fwd_grid_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream(value.device).cuda_stream
-        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                ref_windows.data_ptr(), D, per_head, offsets.data_ptr(), V, mode,
-                kernel_indices.data_ptr(), valid_ratios.data_ptr() if valid_ratios is not None else 0,
-                attn.data_ptr(), *dims, out.data_ptr(), grid.data_ptr(), stream)
-    if rc == _lib.NOT_ELIGIBLE:
-        return None
-    if rc != 0:
-        raise RuntimeError("boxattn_fwd_grid failed with hipError %d" % rc)
-    return out, grid
-
-
-def box_attn_backward_to_boxes(value, spatial_shapes, level_start_index, grid, attn_weight,
-                               grad_output, ref_windows, offsets, kernel_indices, valid_ratios,
-                               angle_mode, need_ref_grad=False):
-    """-> [grad_value, grad_offsets (B,Lq,H,L,V), grad_ref_rows (B,Lq,H,L,5) or None, grad_attn] or
-    None when the fused kernel does not apply (use box_attn_backward + box_grid_backward then).
-    The point-gradient kernel reduces the location gradients to the box gradients itself."""
-    (B, Lq, H, L, P), (D, per_head, V, mode) = _grid_args(ref_windows, offsets, kernel_indices,
-                                                           valid_ratios, angle_mode)
-    dims, loc, (attn,), cdt = _prepare(value, spatial_shapes, level_start_index, grid,
-                                       [attn_weight], [("grad_output", grad_output)])
-    if value.dtype not in (torch.float32, torch.bfloat16) or loc.dtype != torch.float32:
-        return None
-    ws, sh, ls = _sized_buffer(_lib.load().boxattn_bwd_workspace_bytes, value, spatial_shapes,
-                               level_start_index, dims)
-    grad_value = torch.empty_like(value)
-    grad_offsets = torch.empty_like(offsets)
-    grad_rows = torch.empty((B, Lq, H, L, 5), dtype=torch.float32, device=value.device) \
-        if need_ref_grad else None
-    grad_attn = torch.empty(attn_weight.shape, dtype=torch.float32, device=value.device)
-    fn = getattr(_lib.load(), "boxattn_bwd_ws_grid_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream(value.device).cuda_stream
-        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                loc.data_ptr(), attn.data_ptr(), grad_output.data_ptr(), ref_windows.data_ptr(), D,
-                per_head, offsets.data_ptr(), V, mode, kernel_indices.data_ptr(),
-                valid_ratios.data_ptr() if valid_ratios is not None else 0, *dims,
-                grad_value.data_ptr(), grad_offsets.data_ptr(),
-                grad_rows.data_ptr() if grad_rows is not None else 0, grad_attn.data_ptr(),
-                sh.ctypes.data, ls.ctypes.data, ws.data_ptr(), ws.numel(), stream)
-    if rc == _lib.NOT_ELIGIBLE:
-        return None
-    if rc != 0:
-        raise RuntimeError("boxattn_bwd_ws_grid failed with hipError %d" % rc)
-    return [grad_value, grad_offsets, grad_rows, grad_attn]

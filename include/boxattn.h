@@ -188,7 +188,7 @@ int instattn_bwd_ws_bf16(const uint16_t *value, const int64_t *shapes, const int
                         void *stream);
 
 /*
- * ---- reference windows + box offsets -> sampling grid (opt-in; SURVEY.md 8(f) N1, first step) --
+ * ---- reference windows + box offsets -> sampling grid (opt-in) ---------------
  * Everything of the modules' `_where_to_attend` after the box-offset projection
  * (e2edet/module/box_attention.py:63-81 BoxAttention / InstanceAttention, :304-338
  * Box3dAttention) as one kernel each way:
@@ -287,50 +287,6 @@ int instattn_fwd_train_bf16(const uint16_t *value, const int64_t *shapes, const 
 int boxattn_set_variant(int variant);
 
 /*
- * ---- box attention straight from boxes (opt-in; SURVEY.md 8(f) N1, second step) -------------
- * The modules' `_where_to_attend` tail (see boxattn_grid_*) inside the sampling kernels:
- *   boxattn_fwd_grid_*     the forward computes every sample point from its box (reference window
- *                          + predicted offsets; arguments as boxattn_grid_fwd_f32) instead of
- *                          reading a grid, and stores the grid (B,Lq,H,L,P,2) on the way -- the
- *                          backward's kernels read it;
- *   boxattn_bwd_ws_grid_*  the backward of boxattn_bwd_ws_* with the point-gradient kernel reducing
- *                          the location gradients of every (query, head, level) row to grad_offsets
- *                          (B,Lq,H,L,V) and, if grad_ref_rows (B,Lq,H,L,5) is not NULL, the row's
- *                          gradient of the reference window, as boxattn_grid_bwd_f32 would: no
- *                          grad_loc tensor is written or read.
- * Both return BOXATTN_NOT_ELIGIBLE -- nothing was launched -- for shapes their kernels are not
- * built for (the backward needs P = 4, L*P = 8 or 16, a shape the binned algorithm accepts, and
- * enough queries for one launch row); the caller then uses boxattn_grid_* + the plain entries.
- */
-#define BOXATTN_NOT_ELIGIBLE (-2)
-int boxattn_fwd_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                         const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                         int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                         const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
-                         float *out, float *grid, void *stream);
-int boxattn_fwd_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
-                          const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                          int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                          const float *attn, int B, int S, int H, int C, int L, int Lq, int P,
-                          uint16_t *out, float *grid, void *stream);
-int boxattn_bwd_ws_grid_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                            const float *grid, const float *attn, const float *grad_out,
-                            const float *ref, int ref_dim, int ref_per_head, const float *offsets, int V,
-                            int angle_mode, const float *kernel_idx, const float *valid_ratios, int B,
-                            int S, int H, int C, int L, int Lq, int P, float *grad_value,
-                            float *grad_offsets, float *grad_ref_rows, float *grad_attn,
-                            const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                            size_t workspace_bytes, void *stream);
-int boxattn_bwd_ws_grid_bf16(const uint16_t *value, const int64_t *shapes, const int64_t *lsi,
-                             const float *grid, const float *attn, const uint16_t *grad_out,
-                             const float *ref, int ref_dim, int ref_per_head, const float *offsets,
-                             int V, int angle_mode, const float *kernel_idx, const float *valid_ratios,
-                             int B, int S, int H, int C, int L, int Lq, int P, uint16_t *grad_value,
-                             float *grad_offsets, float *grad_ref_rows, float *grad_attn,
-                             const int64_t *shapes_host, const int64_t *lsi_host, void *workspace,
-                             size_t workspace_bytes, void *stream);
-
-/*
  * ---- pointwise work around the operator (opt-in, beyond the reference's native module) ------
  * The modules' softmax over the L*P attention logits of every (query, head) and the zeroing of
  * padded value rows (reference e2edet/module/box_attention.py:222-231), as single passes:
@@ -360,28 +316,27 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      points, 128 ... 1024).  Set it before boxattn_plan_bytes / boxattn_bwd_workspace_bytes: the
  *      layouts depend on it.
  *  11  window-staged kernels of the encoder case (box attention, bf16 or float32 storage, Lq == S, C = 32,
- *      2x2 points, <= 4 levels): 0 library default (on), 1 off (row-gather kernels), 2 on
- *  12  ... margin of its staged windows for the predicted box offsets, in tenths of a quarter of the
- *      expected box (0 = default 25); 13 ... expected box size in pixels of the query's own level
- *      (0 = default 4, BoxeR's reference windows).  Placement only: results do not depend on them.
- *  15  riders: the count pass + scans inside the training forward's launch, the fill pass
- *      inside the point-gradient launch, chunked blocks summed inside the accumulate launch:
- *      0 default (on; chunked blocks are summed inside the accumulate launch wherever the riders run -- maps of up
- *      to 3 072 blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head), and by a
- *      combine launch behind it otherwise), 1 off (launches of their own), 2 on with the combine always a launch of
- *      its own, 3 on with the combine always inside, 4 on with the two-pass binning of ABI 7 (count riders in the
- *      training forward, plan hand-over) instead of the one-pass fill into the ranges of the state buffer
- *  17  window-staged matrix-core forward of the encoder case (same eligibility as 11):
- *      0 library default (on), 1 off (row-gather kernel: faster for uniformly random sampling locations), 2 on
+ *      2x2 points, <= 4 levels; forward and point gradients): 0 library default (on), 1 off
+ *      (row-gather kernels -- the parity cross-check of the two kernel families; faster for uniformly random
+ *      sampling locations, which the BOXATTN_HINT_NOT_LOCAL hint selects per call), 2 on
+ *  15  binning passes of the backward as riders: 0 default -- the fill pass inside the point-gradient
+ *      launch, chunked blocks summed inside the accumulate launch (wherever the riders run -- maps of up to 3 072
+ *      blocks per (image, head) -- or the problem has < 65 536 sample points per (image, head); by a combine launch
+ *      behind it otherwise); box attention on the matrix-core accumulates fills its bins in ONE pass from the ranges in
+ *      the caller's state buffer (*_bwd_ws_*), everything else counts and scans inside the training forward's launch --,
+ *      1 off (launches of their own), 2 on with the combine always a launch of its own, 3 on with the combine always
+ *      inside, 4 on with the two-pass binning of ABI 7 for everything (count riders in the training forward, plan
+ *      hand-over) instead of the one-pass fill
  *  19  float32 box attention, 32 channels per head: the grad_value accumulate -- 0 default: the bf16 matrix cores on
  *      exact three-term splits of rows and weights (float32-accurate, 16-byte records), 1: VALU list
- *      walk (4-byte records), 2: v_mfma_f32_32x32x2_f32 (16-byte records).
+ *      walk (4-byte records; the parity cross-check), 2: v_mfma_f32_32x32x2_f32 (16-byte records).
  *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
  *  20  where the riders sit in their host kernel's grid: (s_count + 1) | (s_fill + 1) << 4 -- a group of 8
  *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | v << 8: 64 v bin workgroups
- *      (= riders) in all; 0 = defaults (all in front, 256).  Set before boxattn_plan_bytes.
- *  21  window-staged FLOAT32 kernels of the encoder case (three workgroups per CU): 0 default (on), 1 off (row-gather
- *      kernels; 11 = 1 switches both storage types off)
+ *      (= riders) in all; 0 = defaults (all in front; 256, or one per ~600 (query, slice) pairs -- 256 ... 768 -- for the
+ *      one-pass fill at encoder sizes).  Set before boxattn_plan_bytes.
+ *  (ABI 8 removed 12 / 13 -- window margins --, 17 and 21 -- staged forward / staged float32 kernels off: 11 = 1
+ *  switches every window-staged kernel off.)
  */
 int boxattn_set_option(int key, int value);
 /* Number of boxattn_set_variant / boxattn_set_option calls so far: lets a binding cache the size queries

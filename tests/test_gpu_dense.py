@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 OPT_DENSE = 11          # boxattn_set_option key: 0 library default, 1 dense kernels off, 2 on
 OPT_RIDERS = 15         # count / scan / fill / combine inside the forward, point-gradient, accumulate launches: 0 on, 1 off
-OPT_DENSE_FWD = 17      # window-staged matrix-core forward: 0 library default (on), 1 off (fwd2_kernel), 2 on
+OPT_DENSE_FWD = OPT_DENSE   # (ABI 8: one switch for the family -- forward and point gradients, both storage types)
 
 
 def _lib():
@@ -34,10 +34,10 @@ def dense_switch():
     lib.boxattn_set_option(OPT_DENSE, old)
 
 
-@pytest.fixture(params=[True, False], ids=["staged_fwd", "gather_fwd"])
+@pytest.fixture(params=[True, False], ids=["staged", "gather"])
 def forward_kernel(request):
-    """Both forward kernels of the encoder case: the window-staged matrix-core forward (default) and the
-    row-gather kernel (fwd2_kernel)."""
+    """Both kernel families of the encoder case: the window-staged kernels (default) and the row-gather kernels
+    (fwd2_kernel / pointgrad2_kernel) -- boxattn_set_option(11)."""
     lib = _lib()
     old = lib.boxattn_set_option(OPT_DENSE_FWD, 2 if request.param else 1)
     yield request.param
@@ -103,8 +103,7 @@ LEVELS = {
 
 @pytest.mark.parametrize("family", ["model", "test", "mixed", "border"])
 @pytest.mark.parametrize("lv", sorted(LEVELS))
-def test_dense_kernels_match_oracle(lv, family, dense_switch, binning, forward_kernel):
-    dense_switch(True)
+def test_dense_kernels_match_oracle(lv, family, binning, forward_kernel):
     inp = make_case(LEVELS[lv], family)
     out, grads = run(inp)
     for name, worst, tol in bench.parity_report(inp, out, grads):
@@ -112,7 +111,7 @@ def test_dense_kernels_match_oracle(lv, family, dense_switch, binning, forward_k
 
 
 OPT_ACC_F32 = 19        # float32 accumulate: 0 bf16 matrix cores on exact three-term splits; 1 VALU; 2 float32 MFMAs
-OPT_DENSE_F32 = 21      # window-staged float32 kernels: 0 on, 1 off
+OPT_DENSE_F32 = OPT_DENSE   # window-staged kernels: 0 on, 1 off (ABI 8: the family's one switch)
 
 
 @pytest.mark.parametrize("acc", [0, 1, 2], ids=["split_bf16_mfma", "valu", "f32_mfma"])
@@ -163,8 +162,7 @@ def test_dense_kernels_random_shapes(seed, dense_switch):
 
 
 @pytest.mark.parametrize("H", [1, 4, 6, 8])
-def test_dense_kernels_head_counts(H, dense_switch, binning, forward_kernel):
-    dense_switch(True)
+def test_dense_kernels_head_counts(H, binning, forward_kernel):
     inp = make_case(LEVELS["4lv"], "mixed", H=H, B=1, seed=3)
     out, grads = run(inp, with_plan=False)
     for name, worst, tol in bench.parity_report(inp, out, grads):

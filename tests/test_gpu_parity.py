@@ -552,12 +552,12 @@ def test_modules_match_reference_goldens():
 
 
 # The opt-in paths of SURVEY.md 8(f) N1 / N3 against the SAME reference goldens:
-# fused_grid 1 (grid kernels), 2 (boxes straight into the sampling kernels), fused_pointwise (one-pass
+# fused_grid (grid kernels), fused_pointwise (one-pass
 # softmax / mask-fill + cast), native bf16 storage.  They are float32 / bf16 paths, so the modules run in
 # float32 here and are compared with the float64 goldens at the float32 (bf16) tolerance.
 @pytest.mark.parametrize("native_bf16", [False, True], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("fused_pointwise", [False, True], ids=["torch_pointwise", "fused_pointwise"])
-@pytest.mark.parametrize("fused_grid", [0, 1, 2])
+@pytest.mark.parametrize("fused_grid", [0, 1])
 def test_fused_module_paths_match_reference_goldens(fused_grid, fused_pointwise, native_bf16):
     from boxer_amd import Box3dAttention, BoxAttention, InstanceAttention
     d, nl, nh = 32, 2, 4
@@ -644,24 +644,20 @@ def _g9_run(name, dtype, fused_grid=0, fused_pointwise=False, native_bf16=False)
         x = x.to(dtype) if x.is_floating_point() else x
         return x.requires_grad_() if grad else x
     query, value, rw = t("query", True), t("value", True), t("ref_windows", True)
-    spies = {"plans": [], "from_boxes": []}
-    orig_train, orig_boxes = ops._forward_train, ops.box_attn_forward_from_boxes
+    spies = {"plans": []}
+    orig_train = ops._forward_train
 
     def spy_train(*a, **k):
         spies["plans"].append(orig_train(*a, **k))
         return spies["plans"][-1]
-
-    def spy_boxes(*a, **k):
-        spies["from_boxes"].append(orig_boxes(*a, **k))
-        return spies["from_boxes"][-1]
-    ops._forward_train, ops.box_attn_forward_from_boxes = spy_train, spy_boxes
+    ops._forward_train = spy_train
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native_bf16):
             outs = m(query, value, dev(g["shapes"]), t("v_mask"), dev(g["lsi"]), t("ratios"), rw)[:n_out]
         loss = sum((o.double() * dev(g["gout%d" % i]).double()).sum() for i, o in enumerate(outs))
         loss.backward()
     finally:
-        ops._forward_train, ops.box_attn_forward_from_boxes = orig_train, orig_boxes
+        ops._forward_train = orig_train
     grads = {"query": query.grad, "value": value.grad, "ref_windows": rw.grad}
     grads.update({"param." + k: p.grad for k, p in m.named_parameters()})
     return m, outs, grads, g, spies
@@ -700,27 +696,21 @@ def test_g9_modules_float64(name):
 
 @pytest.mark.parametrize("native_bf16", [False, True], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("fused_pointwise", [False, True], ids=["torch_pointwise", "fused_pointwise"])
-@pytest.mark.parametrize("fused_grid", [0, 1, 2])
+@pytest.mark.parametrize("fused_grid", [0, 1])
 @pytest.mark.parametrize("name", sorted(G9))
 def test_g9_modules_fast_paths(name, fused_grid, fused_pointwise, native_bf16):
-    """float32 / bf16 storage on the fast kernel families, every opt-in path (fused_grid 1: grid kernels, 2: boxes
-    straight into the sampling kernels; fused_pointwise; native bf16) -- and it is ASSERTED that the fast path ran:
-    the training forward built the binned backward's plan (32 channels per head: eligible), fused_grid = 2 took the
-    from-boxes kernels where they exist (box attention, float32 / bf16), and the bf16 encoder shapes ran the
-    window-staged forward (it is the only kernel that feeds the locality counters of the state buffer)."""
+    """float32 / bf16 storage on the fast kernel families, every opt-in path (fused_grid: grid kernels; fused_pointwise;
+    native bf16) -- and it is ASSERTED that the fast path ran: the training forward went through the training entry
+    (32 channels per head: the binned backward is eligible), and the bf16 encoder shapes ran the window-staged forward
+    (it is the only kernel that feeds the locality counters of the state buffer)."""
     from boxer_amd import ops
     ops.release_workspaces()
     m, outs, grads, g, spies = _g9_run(name, torch.float32, fused_grid, fused_pointwise, native_bf16)
     _g9_check(name, outs, grads, g, 4e-2 if native_bf16 else 2e-4,
               "fused_grid=%s pointwise=%s bf16=%s" % (fused_grid, fused_pointwise, native_bf16),
               rms_only=("ref_windows", "linear_box", "query") if native_bf16 else ())
-    is_box = "inst" not in name
-    if fused_grid == 2 and is_box:
-        assert spies["from_boxes"] and all(r is not None for r in spies["from_boxes"]), \
-            "fused_grid = 2 fell back to the unfused kernels"
-    else:
-        assert spies["plans"] and all(p is not None for p in spies["plans"]), "no plan: not on the binned fast path"
-    if native_bf16 and name.endswith(("_enc", "_enc_masked")) and fused_grid != 2:
+    assert spies["plans"] and all(p is not None for p in spies["plans"]), "no plan: not on the binned fast path"
+    if native_bf16 and name.endswith(("_enc", "_enc_masked")):
         torch.cuda.synchronize()
         counted = sum(int(st[:1024].view(torch.int64).sum().item()) for st in ops._STATE.values())
         assert counted > 0, "the window-staged forward did not run (no locality counts)"
@@ -1353,134 +1343,3 @@ def test_modules_with_fused_pointwise():
 
 
 # ------------------------------------------------------------------ boxes straight into the kernels (N1, step 2)
-def _box_inputs(levels, B, H, angle_mode, per_head, with_ratio, dtype, seed=0):
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    shapes = torch.tensor(levels, device="cuda")
-    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
-    S, L, P, C = int(shapes.prod(1).sum()), len(levels), 4, 32
-    Lq = S
-    V = 5 if angle_mode == 1 else 4
-    D = 5 if angle_mode else 4
-    value = torch.randn(B, S, H, C, device="cuda", generator=g).to(dtype)
-    ref = torch.rand((B, Lq, H, D) if per_head else (B, Lq, D), device="cuda", generator=g)
-    ref[..., 2:4] = 0.02 + 0.1 * ref[..., 2:4]
-    off = torch.randn(B, Lq, H, L, V, device="cuda", generator=g)
-    kidx = torch.tensor([[-.25, -.25], [.25, -.25], [-.25, .25], [.25, .25]], device="cuda")
-    vr = (0.7 + 0.3 * torch.rand(B, 1, 1, L, 1, 2, device="cuda", generator=g)) if with_ratio else None
-    attn = torch.softmax(torch.randn(B, Lq, H, L * P, device="cuda", generator=g), -1).view(B, Lq, H, L, P)
-    gout = torch.randn(B, Lq, H * C, device="cuda", generator=g).to(dtype)
-    return value, shapes, lsi, ref, off, kidx, vr, attn, gout
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("angle_mode,per_head,with_ratio",
-                         [(0, False, False), (0, False, True), (1, False, True), (2, True, False)])
-@pytest.mark.parametrize("levels", [[(80, 64), (40, 32), (20, 16), (10, 8)], [(96, 80), (48, 40)]],
-                         ids=["4lv", "2lv"])
-def test_box_attention_from_boxes_ops(levels, angle_mode, per_head, with_ratio, dtype):
-    """boxattn_fwd_grid_* / boxattn_bwd_ws_grid_*: same grid as the grid kernel (bit-identical: same
-    operations), same output as the forward on that grid, and box gradients equal to
-    box_attn_backward followed by the grid kernel's backward."""
-    from boxer_amd import ops
-    value, shapes, lsi, ref, off, kidx, vr, attn, gout = _box_inputs(
-        levels, 2, 8, angle_mode, per_head, with_ratio, dtype)
-    res = ops.box_attn_forward_from_boxes(value, shapes, lsi, ref, off, kidx, vr, angle_mode, attn)
-    assert res is not None, "the fused forward should take this shape"
-    out, grid = res
-    want_grid = ops.box_grid_forward(ref, off, kidx, vr, angle_mode)
-    assert torch.equal(grid, want_grid)
-    plain = ops.box_attn_forward(value, shapes, lsi, want_grid, attn, 64)
-    if dtype == torch.bfloat16:
-        # bf16 encoder shapes: box_attn_forward takes the window-staged matrix-core forward, the fused call
-        # the row-gather kernel -- the same float32 sums in another order: one bf16 ulp
-        err = (out.float() - plain.float()).abs().max().item()
-        assert err <= 2.0 ** -7 * max(1.0, plain.float().abs().max().item())
-    else:
-        # float32 encoder shapes (round 5): box_attn_forward takes the window-staged float32 forward, the fused call the
-        # row-gather kernel -- the same float32 products summed in another order
-        err = (out - plain).abs().max().item()
-        assert err <= 1e-5 * max(1.0, plain.abs().max().item())
-    fused = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr,
-                                           angle_mode, need_ref_grad=True)
-    assert fused is not None, "the fused backward should take this shape"
-    gv, gl, ga = ops.box_attn_backward(value, shapes, lsi, grid, attn, gout, 64)
-    go, rows = ops.box_grid_backward(ref, off, kidx, vr, angle_mode, gl, need_ref_grad=True)
-    torch.cuda.synchronize()
-    # encoder shapes (bf16, and float32 since round 5): box_attn_backward takes the window-staged point-gradient
-    # kernel, the fused entry point the gather kernel -- same products, another order of the 32-term sums
-    assert (fused[3] - ga).abs().max().item() <= 2e-5 * max(1.0, ga.abs().max().item())
-    # (grad_value: same kernels, but the summation order inside a bin differs from run to run)
-    for got, want, name in ((fused[0].float(), gv.float(), "grad_value"), (fused[1], go, "grad_offsets"),
-                            (fused[2], rows, "grad_ref_rows")):
-        err = (got - want).abs().max().item()
-        tol = 1e-2 if (name == "grad_value" and dtype == torch.bfloat16) else 1e-5
-        assert err <= tol * max(1.0, want.abs().max().item()), (name, err)
-
-
-@pytest.mark.gpu
-def test_boxes_in_backward_with_undersized_workspace(monkeypatch):
-    """ADVICE (round 2): boxattn_bwd_ws_grid_* with a workspace smaller than the binned layout must
-    report "not eligible" before anything is launched -- the atomic fallback would write
-    B*Lq*H*L*P*2 location gradients into the (smaller) grad_offsets buffer."""
-    from boxer_amd import ops
-    levels = [(48, 40), (24, 20), (12, 10), (6, 5)]
-    value, shapes, lsi, ref, off, kidx, vr, attn, gout = _box_inputs(
-        levels, 2, 8, 0, False, False, torch.float32)
-    grid = ops.box_grid_forward(ref, off, kidx, vr, 0)
-    real = ops._sized_buffer
-
-    def small(query, value, shapes, lsi, dims, minimum=256):
-        ws, sh, ls = real(query, value, shapes, lsi, dims, minimum)
-        return ws[: ws.numel() // 2 // 256 * 256], sh, ls
-
-    monkeypatch.setattr(ops, "_sized_buffer", small)
-    res = ops.box_attn_backward_to_boxes(value, shapes, lsi, grid, attn, gout, ref, off, kidx, vr, 0,
-                                         need_ref_grad=True)
-    torch.cuda.synchronize()
-    assert res is None
-
-
-def test_modules_with_grid_inside_the_kernels():
-    """``module.fused_grid = 2``: outputs and parameter gradients of BoxAttention / Box3dAttention
-    as without it -- on an encoder-sized map (the fused kernels run) and on a small decoder shape
-    (the Function falls back to the grid kernels + the plain operator)."""
-    from boxer_amd import Box3dAttention, BoxAttention
-    torch.manual_seed(0)
-    d = 256
-    for levels, Lq in (([(48, 40), (24, 20), (12, 10), (6, 5)], None), ([(12, 9), (6, 5)], 17)):
-        shapes = torch.tensor(levels, device="cuda")
-        lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
-        S, nl = int(shapes.prod(1).sum()), len(levels)
-        B = 2
-        n_q = S if Lq is None else Lq
-        query = torch.randn(B, n_q, d, device="cuda")
-        value = torch.randn(B, S, d, device="cuda")
-        v_mask = torch.rand(B, S, device="cuda") < 0.1
-        ratios = 0.7 + 0.3 * torch.rand(B, 1, 1, nl, 1, 2, device="cuda")
-        ref = (torch.rand(B, n_q, 5, device="cuda") * 0.5 + 0.2).requires_grad_()
-        for cls, kw, native in ((BoxAttention, {}, False), (BoxAttention, {}, True),
-                                (Box3dAttention, {"with_rotation": True}, False),
-                                (Box3dAttention, {"with_rotation": False}, False)):
-            m = cls(d, nl, 8, **kw).cuda()
-            m.native_bf16 = native
-            with torch.no_grad():
-                m.linear_box_weight.normal_(0, 0.05)
-                m.linear_attn_weight.normal_(0, 0.05)
-            rw = ref if cls is Box3dAttention else ref[..., :4]
-            outs = []
-            for fused in (False, 2):
-                m.fused_grid = fused
-                m.zero_grad()
-                ref.grad = None
-                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=native):
-                    res = m(query, value, shapes, v_mask, lsi, ratios, rw)
-                res[0].float().square().sum().backward()
-                outs.append((res[0].detach().float(), ref.grad.clone(),
-                             [p.grad.detach().clone() for p in m.parameters()]))
-            tol = 2e-2 if native else 2e-5
-            scale = max(1.0, outs[0][0].abs().max().item())
-            assert (outs[0][0] - outs[1][0]).abs().max().item() <= tol * scale, cls.__name__
-            assert (outs[0][1] - outs[1][1]).abs().max().item() <= tol * max(
-                1.0, outs[0][1].abs().max().item()), (cls.__name__, "ref grad")
-            for ga, gb in zip(outs[0][2], outs[1][2]):
-                assert (ga - gb).abs().max().item() <= tol * max(1.0, ga.abs().max().item()), cls.__name__

@@ -1,5 +1,5 @@
 """Forward + backward of one BoxAttention module at BoxeR-R50 COCO shapes (encoder: one query per
-pixel; decoder: 300 queries), fused_grid 0 / 1 / 2 x fused_pointwise, bf16 storage under autocast."""
+pixel; decoder: 300 queries), fused_grid 0 / 1 x fused_pointwise, bf16 storage under autocast."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from boxer_amd import BoxAttention, layers
@@ -21,7 +21,7 @@ for name, Lq, ref in (("encoder", S, layers.encoder_ref_windows_2d(levels, B, de
     query = torch.randn(B, Lq, d, device="cuda", requires_grad=True)
     if ONLY and ONLY[0] != name:
         continue
-    for fg in (0, 1, 2):
+    for fg in (0, 1):
         for fp in (False, True):
             if ONLY and (fg, fp) != (int(ONLY[1]), ONLY[2] == "1"):
                 continue
