@@ -158,6 +158,20 @@ struct PlanLayout {
 };
 struct ScratchLayout { size_t records, partials, ctickets, total; };
 
+// Is this a shape whose box-attention backward fills its bins in ONE pass (boxattn_spec.h)?  A property of the dimensions
+// and the switches alone (the plan's layout -- the number of riders -- depends on it).  The ranges of that fill are
+// planned from the PREVIOUS call's counts, so it is for maps whose blocks see about the same number of records from call to
+// call: many records a block (an encoder's one query per pixel: 660 a block at BoxeR-R50 shapes, fixed by the geometry).
+// 300 decoder queries leave ~9 records a block, anywhere: every call outgrows the ranges of the one before (measured, C3'':
+// 104 us a step over changing inputs against 52 with the two-pass riders, profiles/r06_onepass_ab.log).
+constexpr long long kSpecMinRecordsPerBlock = 192;
+inline bool spec_shape(const Dims &d, const BinPlan &p)
+{
+    const int o = opt(kOptRiders);
+    return (o == 0 || o == 2 || o == 3) && p.nblk <= kSpecMaxBlocks && p.min_items == 1 &&
+           3ll * d.Lq * d.L * d.P / 2 >= kSpecMinRecordsPerBlock * p.nblk;
+}
+
 inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
 {
     const size_t ns = (size_t)d.B * d.H;
@@ -166,9 +180,7 @@ inline PlanLayout plan_layout(const Dims &d, const BinPlan &p)
     // ... and at most kScanSub * kScanWgPerSub per slice (the scan's two levels)
     // (a shape whose box-attention backward takes the one-pass fill gets more, shorter riders -- whatever the storage
     // type or operator of THIS call: the layout is a function of the dimensions and the switches alone)
-    const int o15 = opt(kOptRiders);
-    const bool one_pass = (o15 == 0 || o15 == 2 || o15 == 3) && p.nblk <= kSpecMaxBlocks && p.min_items == 1;
-    const long long wg_target = bin_wg_target(one_pass, (long long)d.Lq * (long long)ns);
+    const long long wg_target = bin_wg_target(spec_shape(d, p), (long long)d.Lq * (long long)ns);
     w.q_per_wg = std::max(8, (int)(((long long)d.Lq * (long long)ns + wg_target - 1) / wg_target));
     w.q_per_wg = std::max(w.q_per_wg, (d.Lq + kScanSub * kScanWgPerSub - 1) /
                                           (kScanSub * kScanWgPerSub));
@@ -226,9 +238,8 @@ inline bool riders_ok(const BinPlan &plan, const PlanLayout &w)
 template <typename ST, bool INST> inline bool spec_ok(const Dims &d, const BinPlan &plan, const PlanLayout &pl)
 {
     if (INST || std::is_same<ST, double>::value) return false;
-    const int o = opt(kOptRiders);
-    return (o == 0 || o == 2 || o == 3) && acc_kind<ST, INST>(d) != kAccValu && riders_ok(plan, pl) &&
-           plan.nblk <= kSpecMaxBlocks && (long long)d.Lq * d.P < (1 << 24) && plan.rec_cap < (1 << 28) &&
+    return spec_shape(d, plan) && acc_kind<ST, INST>(d) != kAccValu && riders_ok(plan, pl) &&
+           (long long)d.Lq * d.P < (1 << 24) && plan.rec_cap < (1 << 28) &&
            d.n_qh() * (size_t)d.L * (size_t)d.P < ((size_t)1 << 29);
 }
 

@@ -228,32 +228,32 @@ def test_reference_style_functions_get_the_parked_plan(compiled, dtype, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_one_pass_backward_through_the_compiled_module(compiled, dtype):
-    """The reference's four functions, default switches: box attention's backward fills its bins in one pass from the
-    ranges in the module's per-geometry state buffer -- the forward parks nothing, and from the second step on the
-    backward launches no count / scan / fill pass of its own; gradients are the golden ones in every step."""
+    """The reference's four functions, default switches, an encoder shape (one query per pixel): box attention's
+    backward fills its bins in one pass from the ranges in the module's per-geometry state buffer -- the forward parks
+    nothing, and from the second step on the backward launches no count / scan / fill pass of its own; every step's
+    tensors are the oracle's."""
     import bench
     from boxer_amd import _lib
-    g = golden_io.load("G6_box_ml")
+    bench.WORKLOADS["_compiled_enc"] = ([(37, 53), (19, 27), (10, 14), (5, 7)], "S", 4, "box")
+    try:
+        inp = bench.make_inputs("_compiled_enc", dtype, "cuda", family="model", batch=2, seed=2)
+    finally:
+        del bench.WORKLOADS["_compiled_enc"]
     compiled.release_buffers()
     ref_box, _ = bench.reference_style_functions(compiled)
-    shapes, lsi = _dev(g["shapes"]), _dev(g["lsi"])
-    tol = TOL[dtype]
     for it in range(3):
-        v = _dev(g["value"], dtype).requires_grad_()
-        l = _dev(g["loc"], torch.float32).requires_grad_()
-        a = _dev(g["attn"], torch.float32).requires_grad_()
+        v, l, a = (inp[k].detach().clone().requires_grad_() for k in ("value", "loc", "attn"))
         _lib.profile_begin()
         try:
-            out = ref_box.apply(v, shapes, lsi, l, a, 64)
+            out = ref_box.apply(v, inp["shapes"], inp["lsi"], l, a, 64)
             assert compiled.parked_plans() == 0
-            out.backward(_dev(g["grad_out"], dtype))
+            out.backward(inp["grad_out"])
             torch.cuda.synchronize()
         finally:
             slots = _lib.profile_end()
         assert (slots["bwd_binning"]["launches"] > 0) == (it == 0), (it, slots)
-        _close(out, g["out"], tol, "out")
-        _close(v.grad, g["grad_value"], tol, "grad_value (step %d)" % it)
-        _close(a.grad, g["grad_attn"], max(tol, 1e-4), "grad_attn")
+        for name, worst, tol in bench.parity_report(inp, out, [v.grad, l.grad, a.grad]):
+            assert worst <= tol, (it, name, worst)
 
 
 @pytest.mark.gpu

@@ -1040,7 +1040,8 @@ def test_training_forward_plan(dtype, riders):
     from boxer_amd import _lib, ops
     _lib.set_option("riders", riders)     # 4: the forward counts and scans (a plan buffer); 0: the backward's one-pass fill
                                           # needs none -- the plan object then only carries the forward's hints
-    g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 700, 4, seed=41, lo=-0.2, hi=1.2)
+    # (1 000 queries: ~245 records a block of this map -- the one-pass fill takes shapes with >= 192)
+    g = _seeded([(37, 53), (19, 27), (10, 14), (5, 7)], 2, 8, 32, 1000, 4, seed=41, lo=-0.2, hi=1.2)
     cdt = _cdt(dtype)
     value, loc, attn = dev(g["value"], dtype), dev(g["loc"], cdt), dev(g["attn"], cdt)
     shapes, lsi, gout = dev(g["shapes"]), dev(g["lsi"]), dev(g["grad_out"], dtype)
@@ -1078,7 +1079,7 @@ def test_training_forward_refuses_a_bad_state_buffer():
     import ctypes
     from boxer_amd import _lib
     lib = _lib.load()
-    g = _seeded([(20, 30), (10, 15)], 1, 8, 32, 50, 4, seed=59)
+    g = _seeded([(20, 30), (10, 15)], 1, 8, 32, 800, 4, seed=59)     # (many records a block: a one-pass shape)
     value, loc, attn = dev(g["value"], torch.float32), dev(g["loc"], torch.float32), dev(g["attn"], torch.float32)
     shapes, lsi = dev(g["shapes"]), dev(g["lsi"])
     B, S, H, C = value.shape

@@ -1,5 +1,5 @@
 """One-pass fill under changing inputs: N input sets cycled; prints per-step time and the state's counters {chains run,
-blocks redone} (boxattn_spec.h).   python tools/gpu_onepass_stats.py [sets] [steps] [dtype]"""
+blocks redone} (boxattn_spec.h).   python tools/gpu_onepass_stats.py [sets] [steps] [dtype] [workload]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -29,5 +29,5 @@ for k in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 c1 = counters()
-print("%d sets, %s: %.1f us/step; chains %d, blocks redone %d in %d steps (%.2f per step)" % (
+print(wl, "%d sets, %s: %.1f us/step; chains %d, blocks redone %d in %d steps (%.2f per step)" % (
     n_sets, dtype, dt * 1e6, c1[0] - c0[0], c1[1] - c0[1], steps, (c1[1] - c0[1]) / steps))
