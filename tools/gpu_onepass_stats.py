@@ -7,7 +7,8 @@ from boxer_amd import ops
 n_sets = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[3] if len(sys.argv) > 3 else "bf16"]
-sets = [bench.make_inputs("C2", dtype, "cuda", seed=1000 + i) for i in range(n_sets)]
+wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
+sets = [bench.make_inputs(wl, dtype, "cuda", seed=1000 + i) for i in range(n_sets)]
 fns = [bench.make_step(x, "ops") for x in sets]
 
 

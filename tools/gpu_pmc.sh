@@ -5,7 +5,7 @@ tag=$1; ctrs=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --preheat-s 0 --rotate 0 "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --preheat-s 0 "$@" > $out/bench.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 echo "file: $f"
 python3 - "$f" <<'PY'

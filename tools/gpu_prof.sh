@@ -5,7 +5,7 @@ tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-check --preheat-s 0 --rotate 0 "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-check --preheat-s 0 "$@" > $out/bench.log 2>&1
 tail -1 $out/bench.log
 find $out -name "*kernel_stats*" | head -3
 f=$(find $out -name "*kernel_stats.csv" | head -1)

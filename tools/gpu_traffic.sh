@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c
   mkdir -p $out
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --preheat-s 0 --rotate 0 "$@" > $out/bench.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --preheat-s 0 "$@" > $out/bench.log 2>&1
 done
 python3 - $GRAFT_REPO_ROOT/gpurun_out $tag <<'PY'
 import csv, sys, collections, json, glob, os
