@@ -271,3 +271,26 @@ def test_sparse_decoder_shapes_keep_the_two_pass_riders():
         if it >= 3:
             check(inp, out, grads, "step %d" % it)
     assert counters() == (0, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_degenerate_record_distributions(dtype):
+    """What the ranges are planned from can be anything: no record at all (every location outside the maps), then every
+    point of a level in ONE block (a single range has to take them all: it does not -- redone -- and the call after that
+    plans it: chunked, combined), then ordinary data again.  The oracle's tensors every time."""
+    from boxer_amd import ops
+    ops.release_workspaces()
+    base = make_case(LEVELS4, "S", dtype=dtype, seed=13)
+    outside = dict(base, loc=(base["loc"] * 0 + 7.5).contiguous())
+    one_block = dict(base, loc=(base["loc"] * 0.02 + 0.4).contiguous())      # ~1 x 1 pixels on every level
+    seq = [("ordinary (cold)", base), ("ordinary", base), ("no records", outside), ("no records again", outside),
+           ("one block", one_block), ("one block, planned", one_block), ("one block, planned again", one_block),
+           ("ordinary after one block", base), ("ordinary again", base)]
+    redone = []
+    for what, inp in seq:
+        out, grads = step(inp)
+        check(inp, out, grads, what)
+        redone.append(counters()[1])
+    assert redone[4] > redone[3], "every point in one block: its range was planned for none"
+    assert redone[6] == redone[5], "planned by the same data: nothing to redo"
+    assert redone[8] == redone[7], redone
