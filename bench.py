@@ -5,10 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one box-attention forward + backward (boxer_amd.ops.box_attn_forward +
-box_attn_backward, i.e. the reference's native boundary e2edet.ops) over one per-GPU batch
-of synthetic input, inputs resident in HBM.  The backward includes the grad_value zero-fill
-and, in bf16 mode, the fp32->bf16 conversion of grad_value (they are part of the op).
+One "step" = one box-attention forward + backward through the reference's own API -- autograd Functions in the
+reference's shape (box_attention_func.py:10-64) on the compiled drop-in module's four functions (vision.cpp:7-12;
+``--entry reference``, the default) -- over one per-GPU batch of synthetic input resident in HBM.  Every output element
+is defined by the call (no zero-fill or conversion pass outside it).  The timed steps CYCLE 8 input / upstream-gradient
+sets generated before the timed region (cache-cold, the headline ``value``); the same step replaying one set is
+reported beside it as ``resident``.
 
 Metric (BASELINE.json): Gsample-points/s, one sample point = one (b, query, head, level,
 point) bilinear sample of C=32 channels; NP = B*Lq*H*L*P per step and GPU.
@@ -28,10 +30,11 @@ the parent touches the GPU; the counterpart of the reference's tools/run.py:59-7
 Before anything is timed the step's tensors are compared with the CPU oracle (``--no-check``
 skips it); a failing comparison prints no JSON line and exits non-zero.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-"roofline" (dominant kernel vs the 8 TB/s HBM peak) and "cpu_baseline" (the C restatement of
-the reference kernels on the bench workload -- kind "port" -- plus, inside it, the north star's
-"pure-PyTorch fallback" leg at BASELINE configs[0] (C1); rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: "roofline" (dominant kernel vs the
+8 TB/s HBM peak; step_frac = the whole step), "resident", "cpu_baseline" (the C restatement of the reference kernels on
+the bench workload -- kind "port" -- with the pure-PyTorch leg at BASELINE configs[0] inside) and
+"pytorch_fallback_cpu" (north_star's comparator: the pure-PyTorch formulation on the host cores at the shape of this
+line, 3 iterations); rank 0, N=1 only.
 """
 import argparse
 import json

@@ -2,7 +2,8 @@
 // move no algorithmic bytes) as extra workgroups INSIDE the launches of the kernels that do the
 // operator's work, instead of launches of their own on the critical path:
 //
-//   training forward   [count riders -> per-slice scans by the last arrivers]  inside the forward kernel
+//   training forward   [count riders -> per-slice scans by the last arrivers]  inside the forward kernel (two-pass
+//                      binning; shapes on the one-pass fill of boxattn_spec.h carry nothing here)
 //   backward, launch 1 [fill riders]                                           inside the point-gradient kernel
 //   backward, launch 2 accumulate; the partial tiles of a chunked block are summed by the block's last
 //                      arriver (boxattn_combine.h chunk_finish)
