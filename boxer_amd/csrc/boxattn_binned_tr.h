@@ -322,12 +322,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C <= 32 ? BO
 //   products: w1 (g1, g2, g3), w2 (g1, g2), w3 g1.
 // Wide records {id, x, y, weight}; the next round's rows are requested as soon as this round's have been split (one
 // register buffer).
-template <int C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void binned_accumulate_split_kernel(
+// INST (round 6): instance attention.  A record's upstream row is t = a_s g[query] + a_l g_mask[query, point]
+// (instance_attn_kernel.cuh:139): both rows are gathered, combined in float32 as they arrive and THEN split -- the
+// bilinear weights go to A^T without an attention weight.  Records {point id, x, y, a_s} as for box attention (a_s = the
+// spatial weight); a_l is gathered from `level_w` by the record's point id.  Two row buffers in flight: 2 waves per SIMD.
+struct InstRows {
+    const float *grad_mask;      // (B, Lq, P, H, C)
+    unsigned grad_mask_bytes;
+    const float *w_lv;           // (B, Lq, H, L, P)
+    int P;
+};
+template <int C, bool INST = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INST ? 2 : 3, INST ? 2 : 3))) void binned_accumulate_split_kernel(
     const float *__restrict__ grad_out, unsigned grad_out_bytes, BinPlan plan, int S, int H, int Lq,
     const int4 *__restrict__ items, const int *__restrict__ n_items,
     const int *__restrict__ records, float *__restrict__ grad_value, float *__restrict__ partials, ChunkCombine cc,
-    ZeroRole zr)
+    ZeroRole zr, InstRows inst)
 {
     static_assert(C == 32, "channels per head");
     constexpr int BW = 8, PB = 32, R = 64;
@@ -367,6 +377,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out), 0, grad_out_bytes, 0x00020000);
     const unsigned slice_off = (unsigned)((b * Lq) * H + h) * (unsigned)ROWB;
     const unsigned q_stride = (unsigned)(H * ROWB);
+    // INST: rows of grad_mask (b, q, p, h, :) and the level weights of this slice's points
+    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(INST ? inst.grad_mask : grad_out), 0, INST ? inst.grad_mask_bytes : grad_out_bytes, 0x00020000);
+    const int P = INST ? inst.P : 1, LP = plan.L * P;
+    const unsigned m_slice_off = (unsigned)((b * Lq) * P * H + h) * (unsigned)ROWB;
+    const unsigned m_q_stride = (unsigned)(P * H * ROWB), m_p_stride = (unsigned)(H * ROWB);
+    const float rcp_p = 1.0f / (float)P;
+    const int lp_mask = (1 << plan.lp_bits) - 1;
     const int piece = lane % LPR, jrow = lane / LPR;
     // staging: record jrow (+ 8 per pass), channels 4 piece .. 4 piece + 3 as 4 bf16 = 8 bytes of its plane row
     const unsigned stage_off = (unsigned)(jrow * 64 + piece * 8);
@@ -402,13 +420,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (rr + lane >= item.z) return make_int4(-1, 0, 0, 0);
             return rec[rr + lane];
         };
-        u32x4 rows[NPASS];
+        u32x4 rows[NPASS], rows_m[INST ? NPASS : 1];
+        float as_rows = 0.f, al_rows = 0.f;            // INST: the two attention weights of the records whose rows are in flight
         auto fetch_rows = [&](const int4 &r) {
             const unsigned off = r.x < 0 ? kNoRow : __umul24((unsigned)r.x >> plan.lp_bits, q_stride) + slice_off;
+            unsigned off_m = kNoRow;
+            if constexpr (INST) {
+                const unsigned q = (unsigned)max(r.x, 0) >> plan.lp_bits;
+                const int lp = max(r.x, 0) & lp_mask;
+                int l_, p_;
+                divmod_small(lp, P, rcp_p, l_, p_);
+                off_m = r.x < 0 ? kNoRow : q * m_q_stride + (unsigned)p_ * m_p_stride + m_slice_off;
+                as_rows = r.x < 0 ? 0.f : __int_as_float(r.w);
+                al_rows = r.x < 0 ? 0.f : inst.w_lv[(((size_t)b * Lq + q) * H + h) * LP + lp];
+            }
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const unsigned oj = (unsigned)__shfl((int)off, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
                 rows[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, oj, 0, 0);
+                if constexpr (INST) {
+                    const unsigned om = (unsigned)__shfl((int)off_m, ps * RPP + jrow, 64) + (unsigned)(piece * 16);
+                    rows_m[ps] = __builtin_amdgcn_raw_buffer_load_b128(rsm, om, 0, 0);
+                }
             }
         };
         // x -> its leading bf16 term (packed pairs) and the exact remainder
@@ -435,6 +468,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int ps = 0; ps < NPASS; ++ps) {
                 float x0 = __uint_as_float(rows[ps].x), x1 = __uint_as_float(rows[ps].y);
                 float x2 = __uint_as_float(rows[ps].z), x3 = __uint_as_float(rows[ps].w);
+                if constexpr (INST) {          // t = a_s g + a_l g_mask, in float32, before the split
+                    const float as_j = __shfl(as_rows, ps * RPP + jrow, 64), al_j = __shfl(al_rows, ps * RPP + jrow, 64);
+                    x0 = fmaf(al_j, __uint_as_float(rows_m[ps].x), as_j * x0);
+                    x1 = fmaf(al_j, __uint_as_float(rows_m[ps].y), as_j * x1);
+                    x2 = fmaf(al_j, __uint_as_float(rows_m[ps].z), as_j * x2);
+                    x3 = fmaf(al_j, __uint_as_float(rows_m[ps].w), as_j * x3);
+                }
                 uint2 t1, t2;
                 t1.x = split2(x0, x1); t1.y = split2(x2, x3);
                 t2.x = split2(x0, x1); t2.y = split2(x2, x3);
@@ -444,7 +484,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
             if (more) fetch_rows(rec_n);               // (the row registers are free again: the next round's rows)
             // ---- lane = record: its <= 4 weights, three bf16 terms each
-            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = __int_as_float(rec_c.w);
+            // (INST: the attention weights are in the combined row already)
+            const float x = __int_as_float(rec_c.y), y = __int_as_float(rec_c.z), a = INST ? 1.f : __int_as_float(rec_c.w);
             float h_im, w_im;
             {
 #pragma clang fp contract(off)                   // two roundings, as in locate()

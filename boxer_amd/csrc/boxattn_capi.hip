@@ -356,14 +356,18 @@ int launch_fwd(const ST *value, const int64_t *shapes, const int64_t *lsi,
             // pair, the points spread over the lane groups (any storage type, no atomics)
             if constexpr (INST) {
                 if (gen2 && blocks < 1024 && d.P >= kWave / G) {
-                    const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, 4)
-                                                    : ceil_div_sz(n_qh, 4);
+                    // 8 or more point steps a pair: its points over the four waves of a workgroup
+                    const int steps = ceil_div_sz((size_t)d.P, (size_t)(kWave / G));
+                    const unsigned ws = steps >= 8 ? 4 : steps >= 4 ? 2 : 1;
+                    const size_t ppw = 4 / ws;
+                    const int wblocks = ix.head_xcd ? 8 * ceil_div_sz((size_t)d.B * d.Lq, ppw)
+                                                    : ceil_div_sz(n_qh, ppw);
                     unsigned total = 0;
                     const BinRide ride = place_riders(count_ride, (unsigned)wblocks, &total);
 #define BOXATTN_FWD_WIDE(GG, VV)                                                              \
     hipLaunchKernelGGL((fwd_inst_wide_kernel<ST, GG, VV>), dim3(total), dim3(256), 0, st,     \
                        value, shapes, lsi, loc, w_sp, w_lv, d.S, d.H, d.L, d.Lq, d.P, out,    \
-                       mask, with_grid(ix, wblocks, 1, 1), (unsigned)vbytes, ride);
+                       mask, with_grid(ix, wblocks, 1, 1), (unsigned)vbytes, ride, ws);
                     BOXATTN_GATHER_DISPATCH(cfg, BOXATTN_FWD_WIDE);
 #undef BOXATTN_FWD_WIDE
                     if (count_ride && ride_taken) *ride_taken = true;
@@ -697,6 +701,14 @@ int launch_accumulate(AccKind acc, const ST *grad_out, const ST *grad_mask, cons
         if (acc == kAccF32) {
             launch_accumulate_f32(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
                                   n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st);
+            return finish();
+        }
+    }
+    if constexpr (std::is_same<ST, float>::value && INST && C == 32) {
+        if (acc == kAccSplit) {
+            launch_accumulate_split(grad_out, (size_t)d.B * d.Lq * d.H * C * sizeof(float), plan, d.S, d.H, d.Lq, items,
+                                    n_items, records, grad_value, partials, wg_per_slice, ns8, cc, zr, st, grad_mask,
+                                    (size_t)d.B * d.Lq * d.P * d.H * C * sizeof(float), w_lv, d.P);
             return finish();
         }
     }

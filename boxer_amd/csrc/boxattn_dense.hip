@@ -104,10 +104,17 @@ void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes
 void launch_accumulate_split(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                              const int4 *items, const int *n_items, const int *records, float *grad_value,
                              float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,
-                             hipStream_t st)
+                             hipStream_t st, const float *grad_mask, size_t grad_mask_bytes, const float *w_lv, int P)
 {
-    hipLaunchKernelGGL((binned_accumulate_split_kernel<32>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st, grad_out,
-                       (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc, zr);
+    const InstRows inst{grad_mask, (unsigned)grad_mask_bytes, w_lv, P};
+    if (grad_mask)      // instance attention: two upstream rows per record
+        hipLaunchKernelGGL((binned_accumulate_split_kernel<32, true>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st,
+                           grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc,
+                           zr, inst);
+    else
+        hipLaunchKernelGGL((binned_accumulate_split_kernel<32, false>), dim3(wg_per_slice + plan.zero_workers, ns8), dim3(64), 0, st,
+                           grad_out, (unsigned)grad_out_bytes, plan, S, H, Lq, items, n_items, records, grad_value, partials, cc,
+                           zr, inst);
 }
 
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,

@@ -108,7 +108,8 @@ void launch_accumulate_tr(int C, const uint16_t *grad_out, size_t grad_out_bytes
 void launch_accumulate_split(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,
                              const int4 *items, const int *n_items, const int *records, float *grad_value,
                              float *partials, int wg_per_slice, int ns8, const ChunkCombine &cc, const ZeroRole &zr,
-                             hipStream_t st);
+                             hipStream_t st, const float *grad_mask = nullptr, size_t grad_mask_bytes = 0,
+                             const float *w_lv = nullptr, int P = 1);
 
 // float32 storage, C = 32: the accumulate on v_mfma_f32_32x32x2_f32 (boxattn_binned_tr.h); grad_out below 2 GB
 void launch_accumulate_f32(const float *grad_out, size_t grad_out_bytes, const BinPlan &plan, int S, int H, int Lq,

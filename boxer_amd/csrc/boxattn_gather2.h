@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
     const float *__restrict__ w_sp, const float *__restrict__ w_lv, int S, int H, int L, int Lq,
     int P, ST *__restrict__ out, ST *__restrict__ mask, GatherIdx ix, unsigned value_bytes,
-    BinRide ride)
+    BinRide ride, unsigned ws)
 {
     constexpr int C = VEC * G, NG = kWave / G;
     typedef Row<ST, VEC> RowT;
@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     constexpr int LCH = RowT::kLaneBytes / (int)sizeof(ST);
     // the training forward: the backward's count pass + scans ride in this launch (fwd2_kernel)
     __shared__ int ride_lds[kRideLdsInts];
+    __shared__ float red[kGatherWaves][VEC * G];
     const RideRole role = ride_role(blockIdx.x, ride.grid);
     if (role.rider) {
         bin_count_ride<256>(ride, role.id, ride_lds);
@@ -572,9 +573,12 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
     const LevelRegs lv_regs = levels_request(shapes, lsi, L);           // published below, behind the first loads
 
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    unsigned qh = blk * kGatherWaves + wv;                   // one pair per wave
+    // `ws` (1, 2, 4) waves share a pair: wave `sub` of them takes the point steps sub, sub + ws, ... (with many points a
+    // pair -- 14 x 14: 25 steps of a float32 wave -- one wave per pair is 1 200 long-lived workgroups on 768 slots)
+    const unsigned ppw = kGatherWaves / ws, sub = wv % ws;
+    unsigned qh = blk * ppw + wv / ws;
     if (ix.head_xcd)                                                    // head = XCD (pair_of_lane)
-        qh = ((blk / 8) * kGatherWaves + wv) * (unsigned)H + blk % 8;
+        qh = ((blk / 8) * ppw + wv / ws) * (unsigned)H + blk % 8;
     const bool live = qh < ix.n_qh;                                     // wave-uniform
     qh = min(qh, ix.n_qh - 1u);
     const int slot = lane % G, grp = lane / G;
@@ -603,15 +607,16 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
         const size_t i = pt0 + (size_t)lc * P + p;
         return Ahead{loc2[i], w_sp[i], w_lv[i]};
     };
-    Ahead nxt = request(0);
+    const int pstep = (int)ws * NG;
+    Ahead nxt = request((int)sub * NG);
     levels_commit(lv, lv_regs, L);
-    if (!live) return;
+    if (ws == 1 && !live) return;
 
-    for (int p0 = 0; p0 < P; p0 += NG) {                              // wave-uniform trip count
+    for (int p0 = (int)sub * NG; live && p0 < P; p0 += pstep) {       // wave-uniform trip count
         const int p = p0 + grp;
         const bool have_p = p < P;
         const Ahead cur = nxt;
-        if (p0 + NG < P) nxt = request(p0 + NG);
+        if (p0 + pstep < P) nxt = request(p0 + pstep);
         f32x2 macc[VEC / 2];
 #pragma unroll
         for (int i = 0; i < VEC / 2; ++i) macc[i] = f32x2{0.f, 0.f};
@@ -687,6 +692,24 @@ __global__ __launch_bounds__(256) void fwd_inst_wide_kernel(
             acc[k].x += __shfl_xor(acc[k].x, o, kWave);
             acc[k].y += __shfl_xor(acc[k].y, o, kWave);
         }
+    if (ws > 1) {                                                       // ... and over the pair's waves
+        if (grp == 0) {
+#pragma unroll
+            for (int k = 0; k < VEC / 2; ++k)
+                *reinterpret_cast<f32x2 *>(&red[wv][slot * VEC + 2 * k]) = acc[k];
+        }
+        __syncthreads();
+        if (sub != 0 || !live) return;
+        if (grp == 0) {
+            for (unsigned s = 1; s < ws; ++s)
+#pragma unroll
+                for (int k = 0; k < VEC / 2; ++k) {
+                    const f32x2 o = *reinterpret_cast<const f32x2 *>(&red[wv + s][slot * VEC + 2 * k]);
+                    acc[k].x += o.x;
+                    acc[k].y += o.y;
+                }
+        }
+    }
     if (grp == 0) row_store<ST, VEC, PSB>(out + (size_t)qh * C + slot * LCH, acc);
 }
 

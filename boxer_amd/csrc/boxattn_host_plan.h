@@ -31,8 +31,8 @@ inline int bin_chunk(const Dims &d)
 //            uniformly random ones;
 //   kAccValu everything else (float32, instance attention): binned_accumulate_kernel, 4-byte records, queries
 //            interleaved over the bin workgroups.
-//   kAccSplit float32 box attention, C = 32 (default): binned_accumulate_split_kernel -- the bf16 matrix cores on exact
-//            three-term splits of rows and weights, 16-byte records; boxattn_set_option(19, 1) goes back to kAccValu.
+//   kAccSplit float32 box AND instance attention, C = 32 (default): binned_accumulate_split_kernel -- the bf16 matrix cores
+//            on exact three-term splits of rows and weights, 16-byte records; boxattn_set_option(19, 1) goes back to kAccValu.
 enum AccKind { kAccValu = 0, kAccTr = 1, kAccF32 = 2, kAccSplit = 3 };
 inline bool accumulate_tr_ok(const Dims &d)          // 32-bit row offsets: grad_out below 2 GB
 {
@@ -44,6 +44,7 @@ inline bool f32_matrix_shape_ok(const Dims &d)
     return d.C == 32 && (size_t)d.B * d.Lq * d.H * 32 * 4 < kAccTrMaxBytes && d.Lq < (1 << 24) && d.H * 128 < (1 << 24);
 }
 inline bool f32_mfma_ok(const Dims &d) { return opt(kOptAccF32) == 2 && f32_matrix_shape_ok(d); }
+constexpr size_t kInstSplitMinPoints = 65536;
 inline bool f32_split_ok(const Dims &d) { return opt(kOptAccF32) == 0 && f32_matrix_shape_ok(d); }
 template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
 {
@@ -53,6 +54,15 @@ template <typename ST, bool INST> inline AccKind acc_kind(const Dims &d)
     if constexpr (!INST && std::is_same<ST, float>::value) {
         if (f32_mfma_ok(d)) return kAccF32;
         if (f32_split_ok(d)) return kAccSplit;
+    }
+    if constexpr (INST && std::is_same<ST, float>::value) {
+        // instance attention (round 6): the split kernel's INST flavour -- two upstream rows per record, combined before
+        // the split; grad_mask rows by 32-bit offsets.  Only with many points a slice: the wide records cost the fill 3x
+        // the bytes and the kernel runs at 2 waves per SIMD (C3, 19 k points a slice: 6 % slower than the VALU kernel;
+        // C3', 235 k: accumulate -13 %, step -1.2 %)
+        if (f32_split_ok(d) && (size_t)d.Lq * d.L * d.P >= kInstSplitMinPoints &&
+            (size_t)d.B * d.Lq * d.P * d.H * 32 * 4 < kAccTrMaxBytes)
+            return kAccSplit;
     }
     return kAccValu;
 }

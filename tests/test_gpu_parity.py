@@ -323,6 +323,37 @@ def test_instance_backward_algorithms(cfg, dtype, variant):
     close(glw, want[3], torch.float32, "grad_level")
 
 
+# (the library takes the matrix-core kernel for instance attention from 65 536 points per (image, head) slice up)
+INST_SPLIT_CFGS = [([(20, 30), (10, 15)], 1, 8, 32, 300, 112),                       # 14 x 8 points, two levels
+                   ([(25, 25), (13, 13), (7, 5), (1, 3), (2, 1)], 1, 2, 32, 2000, 8),    # uneven blocks, one-pixel levels
+                   ([(16, 24)], 2, 8, 32, 1100, 64),                                 # heavy bins: chunked work items
+                   FAST_CFGS[0]]                                                     # (below the bound: the VALU kernel)
+
+
+@pytest.mark.parametrize("cfg", INST_SPLIT_CFGS, ids=["two_levels", "uneven", "heavy", "small"])
+def test_float32_instance_matrix_core_accumulate(cfg):
+    """Instance attention, float32, 32 channels per head: grad_value from the bf16 matrix cores -- the two upstream rows of
+    a record (a_s grad_out + a_l grad_mask, instance_attn_kernel.cuh:139) combined in float32 and split into three exact
+    bf16 terms -- against the oracle at the float32 tolerance and against the VALU kernel to summation-order rounding."""
+    from boxer_amd import _lib
+    g = _seeded(*cfg, seed=38, lo=-0.2, hi=1.2)
+    want = oc.instance_attn_backward(g["value"], g["shapes"], g["lsi"], g["loc"], g["spatial_w"], g["level_w"],
+                                     g["grad_out"], g["grad_mask"])
+    res = {}
+    for mode in (0, 1):
+        old = _lib.load().boxattn_set_option(OPT_ACC_F32, mode)
+        try:
+            _, _, gv, gl, gs, glw = run_inst(g, torch.float32, "binned")
+        finally:
+            _lib.load().boxattn_set_option(OPT_ACC_F32, old)
+        res[mode] = gv
+        close(gv, want[0], torch.float32, "grad_value (float32 accumulate %d)" % mode)
+        close(gl, want[1], torch.float32, "grad_loc", ignore=g["on_edge"])
+        close(gs, want[2], torch.float32, "grad_spatial")
+        close(glw, want[3], torch.float32, "grad_level")
+    assert (res[0] - res[1]).abs().max().item() <= 1e-5 * max(1.0, res[1].abs().max().item())
+
+
 @pytest.mark.parametrize("chunk", [64, 192, 1024, 4096])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_binned_backward_records_per_item(dtype, chunk):
