@@ -327,9 +327,10 @@ int boxattn_value_prep_bf16(const uint16_t *value, const unsigned char *mask, lo
  *      1 off (launches of their own), 2 on with the combine always a launch of its own, 3 on with the combine always
  *      inside, 4 on with the two-pass binning of ABI 7 for everything (count riders in the training forward, plan
  *      hand-over) instead of the one-pass fill
- *  19  float32 box attention, 32 channels per head: the grad_value accumulate -- 0 default: the bf16 matrix cores on
- *      exact three-term splits of rows and weights (float32-accurate, 16-byte records), 1: VALU list
- *      walk (4-byte records; the parity cross-check), 2: v_mfma_f32_32x32x2_f32 (16-byte records).
+ *  19  float32, 32 channels per head: the grad_value accumulate -- 0 default: the bf16 matrix cores on exact
+ *      three-term splits of rows and weights (float32-accurate, 16-byte records; instance attention from
+ *      65 536 points per (image, head) slice up), 1: VALU list walk (4-byte records; the parity cross-check),
+ *      2: v_mfma_f32_32x32x2_f32 (16-byte records; box attention only, instance attention takes the VALU walk).
  *      Set before boxattn_bwd_workspace_bytes / *_fwd_train_*.
  *  20  where the riders sit in their host kernel's grid: (s_count + 1) | (s_fill + 1) << 4 -- a group of 8
  *      rider workgroups every 2^s groups of 8 workgroups (s = 0: all in front) -- | v << 8: 64 v bin workgroups

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Time every library under boxer_amd/variants/ (serial schedule, per-kernel HIP-event times).
-#   gpurun -- bash tools/gpu_variants.sh [bench args]
+#   gpurun -- bash tools/gpu_variants.sh [bench args]     (--entry ops: the compiled module links the default library)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for lib in boxer_amd/variants/libboxattn_*.so; do
   name=$(basename $lib .so); name=${name#libboxattn_}
   for dt in ${VARIANT_DTYPES:-bf16 fp32}; do
-    BOXATTN_HIP_LIB=$PWD/$lib timeout 300 python bench.py --steps 300 --warmup 20 --dtype $dt --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+    BOXATTN_HIP_LIB=$PWD/$lib timeout 300 python bench.py --entry ops --steps 300 --warmup 20 --dtype $dt --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.readline()); k=d['roofline']['kernels']
