@@ -182,6 +182,9 @@ SEEDED = [
     # 3 and 5 levels do not fill the lane groups evenly
     ([(11, 9), (6, 5), (3, 2)], 1, 4, 32, 6, 49),
     ([(11, 9), (6, 5), (3, 2), (2, 2), (1, 1)], 2, 2, 32, 3, 36),
+    # ... two waves per pair (head = workgroup mod 8), an odd number of (image, query) rows: the last workgroup's second
+    # pair does not exist
+    ([(11, 9), (6, 5)], 1, 8, 32, 7, 40),
 ]
 
 
