@@ -330,10 +330,11 @@ def test_instance_backward_algorithms(cfg, dtype, variant):
 INST_SPLIT_CFGS = [([(20, 30), (10, 15)], 1, 8, 32, 300, 112),                       # 14 x 8 points, two levels
                    ([(25, 25), (13, 13), (7, 5), (1, 3), (2, 1)], 1, 2, 32, 2000, 8),    # uneven blocks, one-pixel levels
                    ([(16, 24)], 2, 8, 32, 1100, 64),                                 # heavy bins: chunked work items
+                   ([(20, 30), (10, 15)], 2, 8, 32, 700, 49),                        # odd P: one point per fill thread and group
                    FAST_CFGS[0]]                                                     # (below the bound: the VALU kernel)
 
 
-@pytest.mark.parametrize("cfg", INST_SPLIT_CFGS, ids=["two_levels", "uneven", "heavy", "small"])
+@pytest.mark.parametrize("cfg", INST_SPLIT_CFGS, ids=["two_levels", "uneven", "heavy", "odd_p", "small"])
 def test_float32_instance_matrix_core_accumulate(cfg):
     """Instance attention, float32, 32 channels per head: grad_value from the bf16 matrix cores -- the two upstream rows of
     a record (a_s grad_out + a_l grad_mask, instance_attn_kernel.cuh:139) combined in float32 and split into three exact
