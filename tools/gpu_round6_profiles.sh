@@ -26,9 +26,10 @@ for cfg in "C2_bf16_model" "C2_fp32_model --dtype fp32" "C2_bf16_test --inputs t
 done
 bash tools/gpu_workloads.sh > $R/workloads.log 2>&1
 bash tools/gpu_pmc_multi.sh r06sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
-  "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" > /dev/null 2>&1
-python tools/sq_summary.py gpurun_out/pmc_r06sq_1 gpurun_out/pmc_r06sq_2 > $R/pmc_sq.txt 2>&1
-rm -rf gpurun_out/pmc_r06sq_1 gpurun_out/pmc_r06sq_2
+  "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+  "SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU" > /dev/null 2>&1
+python tools/sq_summary.py gpurun_out/pmc_r06sq_1 gpurun_out/pmc_r06sq_2 gpurun_out/pmc_r06sq_3 > $R/pmc_sq.txt 2>&1
+rm -rf gpurun_out/pmc_r06sq_1 gpurun_out/pmc_r06sq_2 gpurun_out/pmc_r06sq_3
 # one-pass fill against the two-pass riders on this box, resident and cache-cold
 ( python tools/gpu_onepass_ab.py bf16 C2; python tools/gpu_onepass_ab.py fp32 C2; python tools/gpu_onepass_ab.py bf16 C2p ) 2>&1 | grep " set" > $R/onepass_ab.log
 python tools/gpu_onepass_stats.py 8 800 bf16 C2 2>&1 | grep sets >> $R/onepass_ab.log
