@@ -18,6 +18,14 @@ __global__ void probe(float *out, int iters, unsigned seed)
                 asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
                              "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7\n"
                              : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+            } else if (MODE == 3) {         // ONE dependent chain
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n"
+                             "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %0, %0, %0, %0\n"
+                             : "+v"(v0));
+            } else if (MODE == 4) {         // TWO dependent chains, interleaved
+                asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n"
+                             "v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n"
+                             : "+v"(v0), "+v"(v1));
             } else if (MODE == 1) {
                 asm volatile("s_add_u32 %0, %0, %0\n s_add_u32 %1, %1, %1\n s_add_u32 %2, %2, %2\n s_add_u32 %3, %3, %3\n"
                              "s_add_u32 %4, %4, %4\n s_add_u32 %5, %5, %5\n s_add_u32 %6, %6, %6\n s_add_u32 %7, %7, %7\n"
@@ -40,8 +48,8 @@ int main()
     hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
     printf("%d CUs, %d kHz\n", cus, clk_khz);
     const int iters = 20000;
-    const char *names[3] = {"V (v_fma only)", "S (s_add only)", "M (alternating)"};
-    for (int mode = 0; mode < 3; ++mode)
+    const char *names[5] = {"V (v_fma, 8 chains)", "S (s_add only)", "M (alternating)", "D (v_fma, ONE chain)", "D2 (v_fma, 2 chains)"};
+    for (int mode = 0; mode < 5; ++mode)
         for (int w : {1, 2, 4, 8}) {
             // w waves per SIMD: a workgroup of 256 threads = one wave per SIMD; w workgroups per CU
             const int blocks = cus * w;
@@ -49,13 +57,15 @@ int main()
             auto launch = [&]() {
                 if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
                 else if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
-                else hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+                else if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+                else if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
+                else hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 1u);
             };
             launch();
             hipEventRecord(a); launch(); hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             const double instr_per_simd = (double)iters * 64 * w;
-            printf("%-18s %d waves/SIMD: %8.1f us  %.2f cycles per instruction and SIMD (at the nominal clock)\n", names[mode], w,
+            printf("%-22s %d waves/SIMD: %8.1f us  %.2f cycles per instruction and SIMD (at the nominal clock)\n", names[mode], w,
                    ms * 1e3, ms * 1e-3 * clk_khz * 1e3 / instr_per_simd);
         }
     return 0;
